@@ -1,0 +1,117 @@
+// Micro-benchmark: issue rate of the integer / fp64 instructions that a 254-bit
+// Montgomery multiplier can be built from on gfx950.  Reports wave-instructions
+// per second per SIMD relative to v_add_u32, both with 8 waves/SIMD (throughput)
+// and 1 wave/SIMD (single-wave issue).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
+  fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+constexpr int CHAINS = 8;
+constexpr int UNROLL = 4;   // x CHAINS instructions per loop iteration
+
+enum Op { ADD_U32, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24,
+          FMA_F64, ADDC_PAIR, FMA_F32, MAD_U32_U16, LSHL_ADD_U64, MUL_U32_U24, MAD_U64_DEP };
+
+template <int OP>
+__global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed) {
+  unsigned a[CHAINS], b[CHAINS];
+  unsigned long long w[CHAINS];
+  double d[CHAINS];
+  for (int i = 0; i < CHAINS; ++i) {
+    a[i] = seed * (i + 3) + threadIdx.x;
+    b[i] = seed ^ (0x9e3779b9u * (i + 1));
+    w[i] = ((unsigned long long)a[i] << 32) | b[i];
+    d[i] = 1.0 + 1e-9 * (double)(a[i] & 0xffff);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+      for (int i = 0; i < CHAINS; ++i) {
+        if constexpr (OP == ADD_U32)
+          asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == MAD_U64_U32)
+          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(b[i]) : "vcc");
+        else if constexpr (OP == MUL_LO_U32)
+          asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == MUL_HI_U32)
+          asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == MAD_U32_U24)
+          asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == MUL_HI_U32_U24)
+          asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == MUL_U32_U24)
+          asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == FMA_F64)
+          asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d[i]) : "v"(d[(i + 1) % CHAINS]));
+        else if constexpr (OP == FMA_F32) {
+          float f = __uint_as_float(a[i]);
+          asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f) : "v"(b[i]));
+          a[i] = __float_as_uint(f);
+        } else if constexpr (OP == ADDC_PAIR)
+          asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc"
+                       : "+v"(a[i]), "+v"(b[i]) : "v"(seed) : "vcc");
+        else if constexpr (OP == MAD_U32_U16)
+          asm volatile("v_mad_u32_u16 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == LSHL_ADD_U64)
+          asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS]));
+        else if constexpr (OP == MAD_U64_DEP)   // single dependent chain through chain 0
+          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[0]) : "v"(a[i]), "v"(b[i]) : "vcc");
+      }
+    }
+  }
+  unsigned r = 0;
+  for (int i = 0; i < CHAINS; ++i) r ^= a[i] ^ b[i] ^ (unsigned)w[i] ^ (unsigned)(w[i] >> 32) ^ (unsigned)__double_as_longlong(d[i]);
+  if (r == 0x12345678u) out[0] = r;   // keep live
+}
+
+template <int OP>
+double run(const char* name, int blocks, int iters, unsigned* out, int instr_per = 1) {
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  k<OP><<<blocks, 256>>>(out, 16, 7u);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CHECK(hipEventRecord(e0));
+    k<OP><<<blocks, 256>>>(out, iters, 7u + rep);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+  }
+  double waves = (double)blocks * 4;
+  double winstr = waves * iters * UNROLL * CHAINS * instr_per;
+  double rate = winstr / (best * 1e-3);      // wave-instr / s chip-wide
+  printf("%-16s blocks=%5d  %8.3f ms  %10.3f Gwinstr/s  => %6.2f cyc/winstr/SIMD @2.4GHz (1024 SIMDs)\n",
+         name, blocks, best, rate * 1e-9, 1024.0 * 2.4e9 / rate);
+  return rate;
+}
+
+int main() {
+  unsigned* out; CHECK(hipMalloc(&out, 4));
+  hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
+  printf("device %s CUs=%d clock=%d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 0: 8 waves/SIMD (2048 blocks of 4 waves on 256 CUs = 8 blocks/CU);  pass 1: 1 wave/SIMD
+    int blocks = pass == 0 ? 256 * 8 : 256;
+    int iters = pass == 0 ? 4000 : 16000;
+    printf("---- %s ----\n", pass == 0 ? "8 waves/SIMD" : "1 wave/SIMD");
+    run<ADD_U32>("v_add_u32", blocks, iters, out);
+    run<FMA_F32>("v_fma_f32", blocks, iters, out);
+    run<MAD_U64_U32>("v_mad_u64_u32", blocks, iters, out);
+    run<MAD_U64_DEP>("v_mad_u64 dep", blocks, iters, out);
+    run<MUL_LO_U32>("v_mul_lo_u32", blocks, iters, out);
+    run<MUL_HI_U32>("v_mul_hi_u32", blocks, iters, out);
+    run<MAD_U32_U24>("v_mad_u32_u24", blocks, iters, out);
+    run<MUL_U32_U24>("v_mul_u32_u24", blocks, iters, out);
+    run<MUL_HI_U32_U24>("v_mul_hi_u32_u24", blocks, iters, out);
+    run<MAD_U32_U16>("v_mad_u32_u16", blocks, iters, out);
+    run<FMA_F64>("v_fma_f64", blocks, iters, out);
+    run<ADDC_PAIR>("add_co+addc", blocks, iters, out, 2);
+    run<LSHL_ADD_U64>("v_lshl_add_u64", blocks, iters, out);
+  }
+  return 0;
+}
