@@ -1,0 +1,98 @@
+/*
+ * g16hip -- C ABI of the MI355X-native MSM / NTT hot path of a Groth16 (BN254) prover.
+ *
+ * Drop-in boundary for codex-storage/nim-groth16 (reference paths relative to /root/reference):
+ * every entry point names the reference proc it replaces.  The reference has no FFI layer of its
+ * own (it is pure Nim calling constantine); INTEGRATION.md shows the `importc` shims that give
+ * these functions the reference's Nim signatures.
+ *
+ * Data layouts (identical to the reference's in-memory types):
+ *   Fr, Fp   : 32 bytes, 4 x u64 little-endian limbs, Montgomery form R = 2^256, canonical (< modulus)
+ *              (groth16/bn128/fields.nim:23-25, io.nim:60-92)
+ *   Fp2      : 64 bytes  = { c0, c1 }                       (fields.nim:27-32)
+ *   G1 affine: 64 bytes  = { x, y : Fp  }, infinity = (0,0)  (curves.nim:33,49)
+ *   G2 affine: 128 bytes = { x, y : Fp2 }, infinity = (0,0)  (curves.nim:34,50)
+ *   "std" scalars: 32 bytes canonical little-endian, NOT Montgomery (the .wtns layout,
+ *              files/witness.nim:14,57-60)
+ *
+ * Error convention: every function returns 0 on success or a negative G16_E* code; nothing
+ * throws or aborts across the boundary (the reference uses `assert`, msm.nim:97, ntt.nim:56-57).
+ * A g16_ctx is used by one host thread at a time; distinct contexts are independent.
+ * Inputs are read-only and not retained after return, except explicitly registered point sets.
+ * There is NO CPU fallback: without a usable HIP device every call fails with G16_ENODEV.
+ */
+#ifndef G16HIP_H
+#define G16HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G16_OK 0
+#define G16_EINVAL (-1)  /* bad argument (null pointer, size mismatch, log2n out of range ...) */
+#define G16_ENODEV (-2)  /* no HIP device / device init failed */
+#define G16_EHIP (-3)    /* a HIP runtime call or kernel failed; see g16_last_error */
+#define G16_ENOMEM (-4)  /* device or host allocation failed */
+#define G16_ESELFTEST (-5)
+
+typedef struct g16_ctx g16_ctx;
+typedef struct g16_points g16_points; /* device-resident point set (ProverPoints member, zkey_types.nim:36-41) */
+
+/* flags for the scalar argument of the MSM calls */
+#define G16_SCALARS_MONT 1u /* Nim seq[Fr] limbs (Montgomery) -- what msm.nim:42-44 `toBig` consumes   */
+#define G16_SCALARS_STD 0u  /* canonical little-endian (raw .wtns values)                              */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int32_t g16_ctx_create(int32_t device, g16_ctx** out);
+void g16_ctx_destroy(g16_ctx* ctx);
+const char* g16_last_error(const g16_ctx* ctx);
+/* run all work of this context on an existing HIP stream (e.g. torch's current stream); NULL = own stream */
+int32_t g16_ctx_set_stream(g16_ctx* ctx, void* hip_stream);
+int32_t g16_ctx_synchronize(g16_ctx* ctx);
+/* layout / constant / arithmetic self-check on the device (sizeof, Montgomery one == frMontR io.nim:91,
+ * gen1 on curve, small known-answer MSM and NTT).  The Nim shim calls it once at start-up. */
+int32_t g16_selftest(g16_ctx* ctx);
+
+/* ---- MSM: replaces msmMultiThreadedG1/G2 (groth16/bn128/msm.nim:89-158) and msmG1/msmG2 (:202-203),
+ *      i.e. constantine's multiScalarMul_vartime + prj.affine (msm.nim:49-54, 76-81) ----------------- */
+/* host pointers in, affine point out (64 / 128 bytes, host).  n == 0 -> infinity (0,0). */
+int32_t g16_msm_g1(g16_ctx* ctx, const void* scalars, uint32_t scalar_flags, const void* points, size_t n,
+                   void* out_affine);
+int32_t g16_msm_g2(g16_ctx* ctx, const void* scalars, uint32_t scalar_flags, const void* points, size_t n,
+                   void* out_affine);
+/* same with scalars and points already resident in device memory (HBM); result to host memory */
+int32_t g16_msm_g1_dev(g16_ctx* ctx, const void* d_scalars, uint32_t scalar_flags, const void* d_points, size_t n,
+                       void* out_affine);
+int32_t g16_msm_g2_dev(g16_ctx* ctx, const void* d_scalars, uint32_t scalar_flags, const void* d_points, size_t n,
+                       void* out_affine);
+/* partial result for multi-GPU sharding (msm.nim:105-119 chunks): 128 / 256 byte XYZZ accumulator
+ * (X, Y, ZZ, ZZZ), Montgomery; combine with g16_g1_sum_partials / g16_g2_sum_partials. */
+int32_t g16_msm_g1_partial_dev(g16_ctx* ctx, const void* d_scalars, uint32_t scalar_flags, const void* d_points,
+                               size_t n, void* out_xyzz);
+int32_t g16_msm_g2_partial_dev(g16_ctx* ctx, const void* d_scalars, uint32_t scalar_flags, const void* d_points,
+                               size_t n, void* out_xyzz);
+/* res = sum of `count` XYZZ partials (host memory, e.g. gathered over RCCL) -> affine; replaces the
+ * `res += sync pending[k]` loop (msm.nim:117-119, 151-153) */
+int32_t g16_g1_sum_partials(g16_ctx* ctx, const void* xyzz, size_t count, void* out_affine);
+int32_t g16_g2_sum_partials(g16_ctx* ctx, const void* xyzz, size_t count, void* out_affine);
+
+/* ---- NTT: replaces forwardNTT / inverseNTT (groth16/math/ntt.nim:55-77, 139-161) ------------------- */
+/* natural order in and out; forward unscaled, inverse includes 1/n; omega = gen28^(2^(28-log2n))
+ * (math/domain.nim:26-33).  src/dst: n = 2^log2n Fr elements (Montgomery), host memory. 0 <= log2n <= 28 */
+int32_t g16_ntt_fr(g16_ctx* ctx, const void* src, void* dst, uint32_t log2n, int32_t inverse);
+int32_t g16_ntt_fr_dev(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int32_t inverse);
+
+/* ---- profiling ---------------------------------------------------------------------------------- */
+/* when enabled, every kernel launch is bracketed by HIP events on the context's stream */
+int32_t g16_profile_enable(g16_ctx* ctx, int32_t on);
+int32_t g16_profile_reset(g16_ctx* ctx);
+/* writes a JSON object {"kernel": {"calls": k, "total_ms": t}, ...} into buf (NUL-terminated) */
+int32_t g16_profile_report(g16_ctx* ctx, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G16HIP_H */

@@ -1,0 +1,174 @@
+"""ctypes binding of libg16hip.so (include/g16hip.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+G16_OK, G16_EINVAL, G16_ENODEV, G16_EHIP, G16_ENOMEM, G16_ESELFTEST = 0, -1, -2, -3, -4, -5
+SCALARS_MONT, SCALARS_STD = 1, 0
+
+# every symbol include/g16hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "g16_ctx_create", "g16_ctx_destroy", "g16_last_error", "g16_ctx_set_stream", "g16_ctx_synchronize",
+    "g16_selftest", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
+    "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
+    "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
+]
+
+
+class G16Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"g16hip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return os.environ.get("G16HIP_LIB", os.path.join(_HERE, "csrc", "libg16hip.so"))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libg16hip.so.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise G16Error(G16_ENODEV, f"{path} not found: build it with `make -C nim_groth16_amd/csrc` "
+                                   "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = ctypes.CDLL(path)
+    vp, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_size_t
+    lib.g16_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    lib.g16_ctx_destroy.argtypes = [vp]
+    lib.g16_ctx_destroy.restype = None
+    lib.g16_last_error.argtypes = [vp]
+    lib.g16_last_error.restype = ctypes.c_char_p
+    lib.g16_ctx_set_stream.argtypes = [vp, vp]
+    lib.g16_ctx_synchronize.argtypes = [vp]
+    lib.g16_selftest.argtypes = [vp]
+    for name in ("g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
+                 "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev"):
+        getattr(lib, name).argtypes = [vp, vp, u32, vp, sz, vp]
+    for name in ("g16_g1_sum_partials", "g16_g2_sum_partials"):
+        getattr(lib, name).argtypes = [vp, vp, sz, vp]
+    lib.g16_ntt_fr.argtypes = [vp, vp, vp, u32, i32]
+    lib.g16_ntt_fr_dev.argtypes = [vp, vp, vp, u32, i32]
+    lib.g16_profile_enable.argtypes = [vp, i32]
+    lib.g16_profile_reset.argtypes = [vp]
+    lib.g16_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
+    for name in SYMBOLS:
+        if name not in ("g16_ctx_destroy", "g16_last_error"):
+            getattr(lib, name).restype = i32
+    _lib = lib
+    return lib
+
+
+def _buf(b):
+    """bytes / bytearray / numpy array / int (device pointer) -> c_void_p-compatible"""
+    if isinstance(b, int):
+        return ctypes.c_void_p(b)
+    if isinstance(b, (bytes, bytearray)):
+        return ctypes.cast(ctypes.c_char_p(bytes(b)), ctypes.c_void_p) if isinstance(b, bytes) else \
+            ctypes.cast((ctypes.c_char * len(b)).from_buffer(b), ctypes.c_void_p)
+    if hasattr(b, "ctypes"):            # numpy
+        return ctypes.c_void_p(b.ctypes.data)
+    raise TypeError(type(b))
+
+
+class Context:
+    """One g16_ctx = one GPU + one stream; used by one host thread at a time (include/g16hip.h)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.g16_ctx_create(device, ctypes.byref(h))
+        if rc != G16_OK:
+            raise G16Error(rc, "g16_ctx_create failed (no usable HIP device?)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.g16_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != G16_OK:
+            raise G16Error(rc, self._lib.g16_last_error(self._h).decode())
+
+    def selftest(self):
+        self._check(self._lib.g16_selftest(self._h))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.g16_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self._lib.g16_ctx_synchronize(self._h))
+
+    # ---- MSM -----------------------------------------------------------------------------------
+    def msm(self, group: int, scalars, points, n: int, mont: bool = True, device: bool = False,
+            partial: bool = False) -> bytes:
+        """group 1 -> G1 (64-byte points), 2 -> G2 (128-byte points).  Returns the affine result
+        bytes (or the XYZZ partial when partial=True)."""
+        psz = 64 if group == 1 else 128
+        out = ctypes.create_string_buffer(2 * psz if partial else psz)
+        if partial:
+            fn = self._lib.g16_msm_g1_partial_dev if group == 1 else self._lib.g16_msm_g2_partial_dev
+        elif device:
+            fn = self._lib.g16_msm_g1_dev if group == 1 else self._lib.g16_msm_g2_dev
+        else:
+            fn = self._lib.g16_msm_g1 if group == 1 else self._lib.g16_msm_g2
+        s = _buf(scalars) if n else None
+        p = _buf(points) if n else None
+        self._check(fn(self._h, s, SCALARS_MONT if mont else SCALARS_STD, p, n, out))
+        return out.raw
+
+    def sum_partials(self, group: int, xyzz: bytes, count: int) -> bytes:
+        psz = 64 if group == 1 else 128
+        out = ctypes.create_string_buffer(psz)
+        fn = self._lib.g16_g1_sum_partials if group == 1 else self._lib.g16_g2_sum_partials
+        self._check(fn(self._h, _buf(xyzz) if count else None, count, out))
+        return out.raw
+
+    # ---- NTT -----------------------------------------------------------------------------------
+    def ntt(self, src, log2n: int, inverse: bool, dst=None, device: bool = False):
+        n = 1 << log2n
+        if device:
+            self._check(self._lib.g16_ntt_fr_dev(self._h, _buf(src), _buf(dst), log2n, 1 if inverse else 0))
+            return None
+        out = ctypes.create_string_buffer(32 * n)
+        self._check(self._lib.g16_ntt_fr(self._h, _buf(src), out, log2n, 1 if inverse else 0))
+        return out.raw
+
+    # ---- profiling -----------------------------------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self._lib.g16_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.g16_profile_reset(self._h))
+
+    def profile_report(self) -> dict:
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self._lib.g16_profile_report(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

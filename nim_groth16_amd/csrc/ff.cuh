@@ -1,0 +1,386 @@
+// BN254 prime-field arithmetic for CDNA4 (gfx950): Fp (base field) and Fr (scalar field).
+//
+// Element layout = the reference's in-memory layout (constantine, 64-bit build; SURVEY 8a,
+// reference groth16/bn128/io.nim:60-92): 256-bit little-endian integer in Montgomery form with
+// R = 2^256, canonical (< modulus).  On the device it is handled as 8 x u32 limbs, which is the
+// same 32 bytes.
+//
+// Multiplication is product-scanning (Comba/FIPS) Montgomery: every 32x32 partial product is ONE
+// v_mad_u64_u32 into a 64-bit column accumulator plus ONE v_addc_co_u32 collecting the carry-out
+// into a third word.  Measured issue cost on MI355X (profiles/r01_ubench_int_issue_rates.txt):
+// v_mad_u64_u32 ~4.9 cycles/wave, v_addc ~2.7 -- so 32-bit limbs with the wide mad beat 24-bit
+// mads and fp64-FMA limb tricks on this chip.  No MFMA: carry-propagated big-int.
+//
+// The same header compiles with g++ (tests/cpu_kernels) so that the exact device formulas can be
+// unit-tested against the oracle without a GPU; the product library only ever runs them on the GPU
+// (and, for the O(1) prover mask algebra that the reference keeps on the host, in host code).
+#pragma once
+#include <stdint.h>
+#include <utility>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FF_HD __host__ __device__ __forceinline__
+#else
+#define FF_HD inline __attribute__((always_inline))
+#endif
+
+namespace g16 {
+
+struct alignas(16) u256 {
+  uint32_t v[8];
+};
+
+// ---- 96-bit column accumulator primitives -------------------------------------------------------
+// (lo:64, hi:32) += a*b
+FF_HD void mac(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(lo), "+v"(hi)
+      : "v"(a), "v"(b)
+      : "vcc");
+#else
+  unsigned __int128 t = (unsigned __int128)lo + (uint64_t)a * b;
+  lo = (uint64_t)t;
+  hi += (uint32_t)(t >> 64);
+#endif
+}
+// same with a wave-uniform multiplier (a modulus limb) held in an SGPR
+FF_HD void mac_k(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(lo), "+v"(hi)
+      : "v"(a), "s"(k)
+      : "vcc");
+#else
+  mac(lo, hi, a, k);
+#endif
+}
+// (lo:64) += a*b, caller knows the sum cannot overflow 64 bits
+FF_HD void mac_nc(uint64_t& lo, uint32_t a, uint32_t b) { lo += (uint64_t)a * b; }
+
+// column shift: (lo,hi) >>= 32
+FF_HD void acc_shift(uint64_t& lo, uint32_t& hi) {
+  lo = (lo >> 32) | ((uint64_t)hi << 32);
+  hi = 0;
+}
+
+#include "ff_mac.inc"
+
+// carry-chain steps: lower to v_add_co/v_addc_co and v_sub_co/v_subb_co chains under hipcc
+FF_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t& c) {
+#if defined(__clang__)
+  unsigned co;
+  uint32_t r = __builtin_addc(a, b, c, &co);
+  c = co;
+  return r;
+#else
+  uint64_t t = (uint64_t)a + b + c;
+  c = (uint32_t)(t >> 32);
+  return (uint32_t)t;
+#endif
+}
+FF_HD uint32_t subc(uint32_t a, uint32_t b, uint32_t& bw) {
+#if defined(__clang__)
+  unsigned bo;
+  uint32_t r = __builtin_subc(a, b, bw, &bo);
+  bw = bo;
+  return r;
+#else
+  uint64_t t = (uint64_t)a - b - bw;
+  bw = (uint32_t)(t >> 63);
+  return (uint32_t)t;
+#endif
+}
+
+// ---- field parameters ---------------------------------------------------------------------------
+// p = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47   (fields.nim:36)
+struct FpParams {
+  static constexpr uint32_t P0 = 0xd87cfd47u, P1 = 0x3c208c16u, P2 = 0x6871ca8du, P3 = 0x97816a91u,
+                            P4 = 0x8181585du, P5 = 0xb85045b6u, P6 = 0xe131a029u, P7 = 0x30644e72u;
+  static constexpr uint32_t INV = 0xe4866389u;  // -p^-1 mod 2^32
+  // R mod p  (= fpMontR, io.nim:87)
+  static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                      0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  // R^2 mod p
+  static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                     0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+};
+// r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001   (fields.nim:37)
+struct FrParams {
+  static constexpr uint32_t P0 = 0xf0000001u, P1 = 0x43e1f593u, P2 = 0x79b97091u, P3 = 0x2833e848u,
+                            P4 = 0x8181585du, P5 = 0xb85045b6u, P6 = 0xe131a029u, P7 = 0x30644e72u;
+  static constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
+  // R mod r  (= frMontR, io.nim:91)
+  static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                      0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  // R^2 mod r
+  static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                     0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+};
+
+template <class PR>
+struct Field {
+  using T = u256;
+  using Params = PR;
+
+  template <int I>
+  static FF_HD constexpr uint32_t P() {
+    if constexpr (I == 0) return PR::P0;
+    else if constexpr (I == 1) return PR::P1;
+    else if constexpr (I == 2) return PR::P2;
+    else if constexpr (I == 3) return PR::P3;
+    else if constexpr (I == 4) return PR::P4;
+    else if constexpr (I == 5) return PR::P5;
+    else if constexpr (I == 6) return PR::P6;
+    else return PR::P7;
+  }
+  static FF_HD uint32_t Pi(int i) {
+    switch (i) {
+      case 0: return PR::P0; case 1: return PR::P1; case 2: return PR::P2; case 3: return PR::P3;
+      case 4: return PR::P4; case 5: return PR::P5; case 6: return PR::P6; default: return PR::P7;
+    }
+  }
+
+  static FF_HD T zero() {
+    T r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+    return r;
+  }
+  static FF_HD T one() {
+    T r;
+    r.v[0] = PR::ONE[0]; r.v[1] = PR::ONE[1]; r.v[2] = PR::ONE[2]; r.v[3] = PR::ONE[3];
+    r.v[4] = PR::ONE[4]; r.v[5] = PR::ONE[5]; r.v[6] = PR::ONE[6]; r.v[7] = PR::ONE[7];
+    return r;
+  }
+  static FF_HD T r2() {
+    T r;
+    r.v[0] = PR::R2[0]; r.v[1] = PR::R2[1]; r.v[2] = PR::R2[2]; r.v[3] = PR::R2[3];
+    r.v[4] = PR::R2[4]; r.v[5] = PR::R2[5]; r.v[6] = PR::R2[6]; r.v[7] = PR::R2[7];
+    return r;
+  }
+  static FF_HD bool is_zero(const T& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i];
+    return o == 0;
+  }
+  static FF_HD bool eq(const T& a, const T& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+  }
+
+  // r = a - p, returns borrow (1 if a < p)
+  static FF_HD uint32_t sub_p(T& r, const T& a) {
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = subc(a.v[i], Pi(i), bw);
+    return bw;
+  }
+  // canonical reduce of a value known to be < 2p
+  static FF_HD T reduce_once(const T& a) {
+    T t;
+    uint32_t borrow = sub_p(t, a);
+    T r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = borrow ? a.v[i] : t.v[i];
+    return r;
+  }
+  static FF_HD T add(const T& a, const T& b) {
+    T s;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s.v[i] = addc(a.v[i], b.v[i], c);
+    return reduce_once(s);  // a+b < 2p < 2^255: no carry out of 256 bits
+  }
+  static FF_HD T sub(const T& a, const T& b) {
+    T d, t, r;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d.v[i] = subc(a.v[i], b.v[i], bw);
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.v[i] = addc(d.v[i], Pi(i), c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = bw ? t.v[i] : d.v[i];  // borrow -> add p back
+    return r;
+  }
+  static FF_HD T neg(const T& a) {
+    T r;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = subc(Pi(i), a.v[i], bw);
+    bool z = is_zero(a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = z ? 0u : r.v[i];
+    return r;
+  }
+  static FF_HD T dbl(const T& a) { return add(a, a); }
+  // a/2 mod p  (constantine div2, used by the reference's inverse NTT: ntt.nim:111-112,121)
+  static FF_HD T div2(const T& a) {
+    uint32_t mask = (a.v[0] & 1) ? 0xffffffffu : 0u;
+    uint32_t s[9];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = addc(a.v[i], Pi(i) & mask, c);
+    s[8] = c;
+    T r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (s[i] >> 1) | (s[i + 1] << 31);
+    return r;
+  }
+
+  // ---- product-scanning Montgomery ---------------------------------------------------------------
+  // column K of a*b: sum_{i=S}^{S+n-1} a_i * b_{K-i}
+  template <int K, int S, int... I>
+  static FF_HD void col_ab(uint64_t& lo, uint32_t& hi, const T& a, const T& b, std::integer_sequence<int, I...>) {
+    macv(lo, hi, a.v[S + I]..., b.v[K - S - I]...);
+  }
+  // column K of m*p: sum_{i=S}^{S+n-1} m_i * p_{K-i}
+  template <int K, int S, int... I>
+  static FF_HD void col_mp(uint64_t& lo, uint32_t& hi, const uint32_t (&m)[8], std::integer_sequence<int, I...>) {
+    macs(lo, hi, m[S + I]..., P<K - S - I>()...);
+  }
+  template <int K>
+  static FF_HD void mul_col_lo(uint64_t& lo, uint32_t& hi, const T& a, const T& b, uint32_t (&m)[8]) {
+    col_ab<K, 0>(lo, hi, a, b, std::make_integer_sequence<int, K + 1>{});
+    if constexpr (K > 0) col_mp<K, 0>(lo, hi, m, std::make_integer_sequence<int, K>{});
+    m[K] = (uint32_t)lo * PR::INV;
+    macs(lo, hi, m[K], P<0>());
+    acc_shift(lo, hi);
+  }
+  template <int K>
+  static FF_HD void mul_col_hi(uint64_t& lo, uint32_t& hi, const T& a, const T& b, const uint32_t (&m)[8], T& r) {
+    if constexpr (K < 15) {
+      col_ab<K, K - 7>(lo, hi, a, b, std::make_integer_sequence<int, 15 - K>{});
+      col_mp<K, K - 7>(lo, hi, m, std::make_integer_sequence<int, 15 - K>{});
+    }
+    r.v[K - 8] = (uint32_t)lo;
+    acc_shift(lo, hi);
+  }
+  // Montgomery product a*b/R mod p.  128 v_mad_u64_u32 + 128 v_addc + 8 v_mul_lo.
+  static FF_HD T mul(const T& a, const T& b) {
+    uint32_t m[8];
+    T r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    mul_col_lo<0>(lo, hi, a, b, m); mul_col_lo<1>(lo, hi, a, b, m);
+    mul_col_lo<2>(lo, hi, a, b, m); mul_col_lo<3>(lo, hi, a, b, m);
+    mul_col_lo<4>(lo, hi, a, b, m); mul_col_lo<5>(lo, hi, a, b, m);
+    mul_col_lo<6>(lo, hi, a, b, m); mul_col_lo<7>(lo, hi, a, b, m);
+    mul_col_hi<8>(lo, hi, a, b, m, r); mul_col_hi<9>(lo, hi, a, b, m, r);
+    mul_col_hi<10>(lo, hi, a, b, m, r); mul_col_hi<11>(lo, hi, a, b, m, r);
+    mul_col_hi<12>(lo, hi, a, b, m, r); mul_col_hi<13>(lo, hi, a, b, m, r);
+    mul_col_hi<14>(lo, hi, a, b, m, r); mul_col_hi<15>(lo, hi, a, b, m, r);
+    return reduce_once(r);  // inputs < p  =>  result < 2p
+  }
+  static FF_HD T sqr(const T& a) { return mul(a, a); }
+
+  // Montgomery reduction alone: a/R mod p  (Montgomery form -> standard form; msm.nim:42-44 `toBig`)
+  template <int K>
+  static FF_HD void red_col_lo(uint64_t& lo, uint32_t& hi, const T& a, uint32_t (&m)[8]) {
+    if constexpr (K > 0) col_mp<K, 0>(lo, hi, m, std::make_integer_sequence<int, K>{});
+    uint64_t old = lo;
+    lo += a.v[K];
+    hi += (lo < old) ? 1u : 0u;
+    m[K] = (uint32_t)lo * PR::INV;
+    macs(lo, hi, m[K], P<0>());
+    acc_shift(lo, hi);
+  }
+  template <int K>
+  static FF_HD void red_col_hi(uint64_t& lo, uint32_t& hi, const uint32_t (&m)[8], T& r) {
+    if constexpr (K < 15) col_mp<K, K - 7>(lo, hi, m, std::make_integer_sequence<int, 15 - K>{});
+    r.v[K - 8] = (uint32_t)lo;
+    acc_shift(lo, hi);
+  }
+  static FF_HD T from_mont(const T& a) {
+    uint32_t m[8];
+    T r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    red_col_lo<0>(lo, hi, a, m); red_col_lo<1>(lo, hi, a, m); red_col_lo<2>(lo, hi, a, m);
+    red_col_lo<3>(lo, hi, a, m); red_col_lo<4>(lo, hi, a, m); red_col_lo<5>(lo, hi, a, m);
+    red_col_lo<6>(lo, hi, a, m); red_col_lo<7>(lo, hi, a, m);
+    red_col_hi<8>(lo, hi, m, r); red_col_hi<9>(lo, hi, m, r); red_col_hi<10>(lo, hi, m, r);
+    red_col_hi<11>(lo, hi, m, r); red_col_hi<12>(lo, hi, m, r); red_col_hi<13>(lo, hi, m, r);
+    red_col_hi<14>(lo, hi, m, r); red_col_hi<15>(lo, hi, m, r);
+    return reduce_once(r);
+  }
+  static FF_HD T to_mont(const T& a) { return mul(a, r2()); }
+
+  // a^e for a 256-bit exponent given as 8 limbs (vartime; exponents here are public constants)
+  static FF_HD T pow(const T& a, const uint32_t (&e)[8]) {
+    T r = one();
+    bool started = false;
+    for (int i = 7; i >= 0; --i) {
+      for (int b = 31; b >= 0; --b) {
+        if (started) r = sqr(r);
+        if ((e[i] >> b) & 1) {
+          r = started ? mul(r, a) : a;
+          started = true;
+        }
+      }
+    }
+    return r;
+  }
+  // a^(p-2)   (0 -> 0)
+  static FF_HD T inv(const T& a) {
+    uint32_t e[8];
+    e[0] = PR::P0 - 2; e[1] = PR::P1; e[2] = PR::P2; e[3] = PR::P3;
+    e[4] = PR::P4; e[5] = PR::P5; e[6] = PR::P6; e[7] = PR::P7;
+    return pow(a, e);
+  }
+  static FF_HD T mul_small(const T& a, uint32_t k) {  // k in {2,3,4,8}: via doublings/adds
+    T r = a;
+    if (k == 2) return dbl(a);
+    if (k == 3) return add(dbl(a), a);
+    if (k == 4) return dbl(dbl(a));
+    if (k == 8) return dbl(dbl(dbl(a)));
+    (void)r;
+    return a;
+  }
+};
+
+using Fp = Field<FpParams>;
+using Fr = Field<FrParams>;
+
+// ---- Fp2 = Fp[u]/(u^2+1): (c0, c1), 64 bytes  (fields.nim:27-32, coords:[i,u]) -------------------
+struct fp2_t {
+  u256 c0, c1;
+};
+
+struct Fp2 {
+  using T = fp2_t;
+  static FF_HD T zero() { return T{Fp::zero(), Fp::zero()}; }
+  static FF_HD T one() { return T{Fp::one(), Fp::zero()}; }
+  static FF_HD bool is_zero(const T& a) { return Fp::is_zero(a.c0) && Fp::is_zero(a.c1); }
+  static FF_HD bool eq(const T& a, const T& b) { return Fp::eq(a.c0, b.c0) && Fp::eq(a.c1, b.c1); }
+  static FF_HD T add(const T& a, const T& b) { return T{Fp::add(a.c0, b.c0), Fp::add(a.c1, b.c1)}; }
+  static FF_HD T sub(const T& a, const T& b) { return T{Fp::sub(a.c0, b.c0), Fp::sub(a.c1, b.c1)}; }
+  static FF_HD T neg(const T& a) { return T{Fp::neg(a.c0), Fp::neg(a.c1)}; }
+  static FF_HD T dbl(const T& a) { return T{Fp::dbl(a.c0), Fp::dbl(a.c1)}; }
+  // Karatsuba: 3 base-field products
+  static FF_HD T mul(const T& a, const T& b) {
+    u256 v0 = Fp::mul(a.c0, b.c0);
+    u256 v1 = Fp::mul(a.c1, b.c1);
+    u256 s = Fp::mul(Fp::add(a.c0, a.c1), Fp::add(b.c0, b.c1));
+    return T{Fp::sub(v0, v1), Fp::sub(Fp::sub(s, v0), v1)};
+  }
+  // complex squaring: 2 base-field products
+  static FF_HD T sqr(const T& a) {
+    u256 t = Fp::mul(a.c0, a.c1);
+    u256 c0 = Fp::mul(Fp::add(a.c0, a.c1), Fp::sub(a.c0, a.c1));
+    return T{c0, Fp::dbl(t)};
+  }
+  static FF_HD T inv(const T& a) {
+    u256 n = Fp::add(Fp::sqr(a.c0), Fp::sqr(a.c1));
+    u256 d = Fp::inv(n);
+    return T{Fp::mul(a.c0, d), Fp::neg(Fp::mul(a.c1, d))};
+  }
+  static FF_HD T mul_small(const T& a, uint32_t k) { return T{Fp::mul_small(a.c0, k), Fp::mul_small(a.c1, k)}; }
+};
+
+}  // namespace g16

@@ -1,0 +1,105 @@
+// Internal declarations shared by the translation units of libg16hip.so (not part of the C ABI).
+#pragma once
+#include "../../include/g16hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+
+struct ProfEntry {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+
+struct g16_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // growable device buffers
+  struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+  };
+  Buf ws;        // MSM workspace
+  Buf stage_s;   // staged scalars (host-pointer API)
+  Buf stage_p;   // staged points
+  Buf stage_o;   // result slot
+  Buf ntt_tw;    // twiddle table
+  Buf ntt_tmp;   // ping-pong buffer
+  uint32_t tw_log2n = 0xffffffffu;
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+  std::vector<hipEvent_t> free_events;
+};
+
+#define HIPCHK(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e__ = (call);                                                                   \
+    if (e__ != hipSuccess) {                                                                   \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                         \
+      return e__ == hipErrorOutOfMemory ? G16_ENOMEM : G16_EHIP;                               \
+    }                                                                                          \
+  } while (0)
+
+inline int32_t ensure(g16_ctx* ctx, g16_ctx::Buf& b, size_t bytes) {
+  if (b.bytes >= bytes) return G16_OK;
+  if (b.p) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  size_t want = bytes + bytes / 8 + 4096;
+  HIPCHK(ctx, hipMalloc(&b.p, want));
+  b.bytes = want;
+  return G16_OK;
+}
+
+// ---- profiling helpers ----------------------------------------------------------------------------
+struct ProfScope {
+  g16_ctx* ctx;
+  bool on;
+  ProfEntry e;
+  ProfScope(g16_ctx* c, const char* name) : ctx(c), on(c->profiling) {
+    if (!on) return;
+    e.name = name;
+    auto get = [&](hipEvent_t& ev) {
+      if (!ctx->free_events.empty()) {
+        ev = ctx->free_events.back();
+        ctx->free_events.pop_back();
+      } else {
+        (void)hipEventCreate(&ev);
+      }
+    };
+    get(e.e0);
+    get(e.e1);
+    (void)hipEventRecord(e.e0, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e.e1, ctx->stream);
+    ctx->prof.push_back(e);
+  }
+};
+#define KLAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                    \
+  do {                                                                                         \
+    ProfScope ps__(ctx, name);                                                                 \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, (ctx)->stream, __VA_ARGS__);    \
+  } while (0)
+
+
+// implemented in msm_g1.hip / msm_g2.hip / ntt.hip
+int32_t g16_msm_device_g1(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
+                          void* d_out_aff, void* d_out_acc);
+int32_t g16_msm_device_g2(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
+                          void* d_out_aff, void* d_out_acc);
+int32_t g16_sum_partials_device_g1(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
+int32_t g16_sum_partials_device_g2(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
+int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse);

@@ -1,0 +1,268 @@
+// Host side of the C ABI (include/g16hip.h): context, HBM workspace, launch sequences.
+// No CPU compute path exists here: if HIP is unavailable every call returns G16_ENODEV.
+#include "g16_internal.hpp"
+#include "ec.cuh"
+
+using namespace g16;
+
+// ---- context ------------------------------------------------------------------------------------
+extern "C" int32_t g16_ctx_create(int32_t device, g16_ctx** out) {
+  if (!out) return G16_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return G16_ENODEV;
+  if (device < 0 || device >= ndev) return G16_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) return G16_ENODEV;
+  g16_ctx* ctx = new (std::nothrow) g16_ctx();
+  if (!ctx) return G16_ENOMEM;
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return G16_ENODEV;
+  }
+  ctx->own_stream = true;
+  *out = ctx;
+  return G16_OK;
+}
+
+extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (g16_ctx::Buf* b : {&ctx->ws, &ctx->stage_s, &ctx->stage_p, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp})
+    if (b->p) (void)hipFree(b->p);
+  for (auto& e : ctx->prof) {
+    (void)hipEventDestroy(e.e0);
+    (void)hipEventDestroy(e.e1);
+  }
+  for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* g16_last_error(const g16_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int32_t g16_ctx_set_stream(g16_ctx* ctx, void* hip_stream) {
+  if (!ctx) return G16_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream) {
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+  }
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+  } else {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return G16_OK;
+}
+
+extern "C" int32_t g16_ctx_synchronize(g16_ctx* ctx) {
+  if (!ctx) return G16_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+
+extern "C" int32_t g16_profile_enable(g16_ctx* ctx, int32_t on) {
+  if (!ctx) return G16_EINVAL;
+  ctx->profiling = on != 0;
+  return G16_OK;
+}
+extern "C" int32_t g16_profile_reset(g16_ctx* ctx) {
+  if (!ctx) return G16_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& e : ctx->prof) {
+    ctx->free_events.push_back(e.e0);
+    ctx->free_events.push_back(e.e1);
+  }
+  ctx->prof.clear();
+  return G16_OK;
+}
+extern "C" int32_t g16_profile_report(g16_ctx* ctx, char* buf, size_t buflen) {
+  if (!ctx || !buf || buflen < 3) return G16_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::map<std::string, std::pair<int, double>> agg;
+  for (auto& e : ctx->prof) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) {
+      auto& a = agg[e.name];
+      a.first++;
+      a.second += ms;
+    }
+  }
+  std::string s = "{";
+  bool first = true;
+  for (auto& kv : agg) {
+    char tmp[256];
+    snprintf(tmp, sizeof tmp, "%s\"%s\": {\"calls\": %d, \"total_ms\": %.6f}", first ? "" : ", ", kv.first.c_str(),
+             kv.second.first, kv.second.second);
+    s += tmp;
+    first = false;
+  }
+  s += "}";
+  if (s.size() + 1 > buflen) return G16_EINVAL;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return G16_OK;
+}
+
+template <class C>
+static int32_t msm_entry(g16_ctx* ctx, const void* scalars, uint32_t flags, const void* points, size_t n, void* out,
+                         bool on_device, bool partial, const char* tag) {
+  if (!ctx) return G16_EINVAL;
+  if (!out || (n > 0 && (!scalars || !points))) {
+    ctx->err = "null pointer argument";
+    return G16_EINVAL;
+  }
+  if (n >= (size_t(1) << 27)) {
+    ctx->err = "n too large (must be < 2^27)";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t out_bytes = partial ? sizeof(typename C::Acc) : sizeof(typename C::Aff);
+  if (n == 0) {  // msm.nim:117: the sum starts from infG1 / infG2 = (0,0); XYZZ infinity is all-zero as well
+    memset(out, 0, out_bytes);
+    return G16_OK;
+  }
+  const void* d_s = scalars;
+  const void* d_p = points;
+  int32_t rc;
+  if (!on_device) {
+    if ((rc = ensure(ctx, ctx->stage_s, n * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_p, n * sizeof(typename C::Aff)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_s.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_p.p, points, n * sizeof(typename C::Aff), hipMemcpyHostToDevice,
+                               ctx->stream));
+    d_s = ctx->stage_s.p;
+    d_p = ctx->stage_p.p;
+  }
+  if ((rc = ensure(ctx, ctx->stage_o, 512))) return rc;
+  auto* d_aff = partial ? nullptr : (typename C::Aff*)ctx->stage_o.p;
+  auto* d_acc = partial ? (typename C::Acc*)ctx->stage_o.p : nullptr;
+  rc = sizeof(typename C::Aff) == 64 ? g16_msm_device_g1(ctx, d_s, flags, d_p, n, d_aff, d_acc)
+                                     : g16_msm_device_g2(ctx, d_s, flags, d_p, n, d_aff, d_acc);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_o.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+
+extern "C" int32_t g16_msm_g1(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* out) {
+  return msm_entry<G1>(ctx, s, f, p, n, out, false, false, "g1");
+}
+extern "C" int32_t g16_msm_g2(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* out) {
+  return msm_entry<G2>(ctx, s, f, p, n, out, false, false, "g2");
+}
+extern "C" int32_t g16_msm_g1_dev(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* out) {
+  return msm_entry<G1>(ctx, s, f, p, n, out, true, false, "g1");
+}
+extern "C" int32_t g16_msm_g2_dev(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* out) {
+  return msm_entry<G2>(ctx, s, f, p, n, out, true, false, "g2");
+}
+extern "C" int32_t g16_msm_g1_partial_dev(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n,
+                                          void* out) {
+  return msm_entry<G1>(ctx, s, f, p, n, out, true, true, "g1");
+}
+extern "C" int32_t g16_msm_g2_partial_dev(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n,
+                                          void* out) {
+  return msm_entry<G2>(ctx, s, f, p, n, out, true, true, "g2");
+}
+
+template <class C>
+static int32_t sum_partials(g16_ctx* ctx, const void* xyzz, size_t count, void* out) {
+  if (!ctx) return G16_EINVAL;
+  if (!out || (count && !xyzz) || count > 4096) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int32_t rc;
+  size_t bytes = count * sizeof(typename C::Acc);
+  if ((rc = ensure(ctx, ctx->stage_p, bytes + 256))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_o, 512))) return rc;
+  if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->stage_p.p, xyzz, bytes, hipMemcpyHostToDevice, ctx->stream));
+  rc = sizeof(typename C::Aff) == 64 ? g16_sum_partials_device_g1(ctx, ctx->stage_p.p, (uint32_t)count, ctx->stage_o.p)
+                                     : g16_sum_partials_device_g2(ctx, ctx->stage_p.p, (uint32_t)count, ctx->stage_o.p);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_o.p, sizeof(typename C::Aff), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+extern "C" int32_t g16_g1_sum_partials(g16_ctx* ctx, const void* x, size_t count, void* out) {
+  return sum_partials<G1>(ctx, x, count, out);
+}
+extern "C" int32_t g16_g2_sum_partials(g16_ctx* ctx, const void* x, size_t count, void* out) {
+  return sum_partials<G2>(ctx, x, count, out);
+}
+
+// ---- NTT ------------------------------------------------------------------------------------------
+extern "C" int32_t g16_ntt_fr_dev(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int32_t inverse) {
+  if (!ctx) return G16_EINVAL;
+  if (!d_src || !d_dst || log2n > 28) {
+    ctx->err = "bad argument (null pointer or log2n > 28)";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return g16_ntt_device(ctx, d_src, d_dst, log2n, inverse ? 1 : 0);
+}
+
+extern "C" int32_t g16_ntt_fr(g16_ctx* ctx, const void* src, void* dst, uint32_t log2n, int32_t inverse) {
+  if (!ctx) return G16_EINVAL;
+  if (!src || !dst || log2n > 28) {
+    ctx->err = "bad argument (null pointer or log2n > 28)";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t(1) << log2n) * 32;
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->stage_s, bytes))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_p, bytes))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->stage_s.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = g16_ntt_device(ctx, ctx->stage_s.p, ctx->stage_p.p, log2n, inverse ? 1 : 0))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(dst, ctx->stage_p.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+
+// ---- selftest -------------------------------------------------------------------------------------
+__global__ void selftest_kernel(uint32_t* out) {
+  if (threadIdx.x != 0) return;
+  uint32_t ok = 1;
+  // Montgomery one * one == one ; from_mont(one) == 1 ; gen1 = (1,2) on y^2 = x^3 + 3
+  u256 one = Fp::one();
+  ok &= Fp::eq(Fp::mul(one, one), one);
+  u256 s1 = Fr::from_mont(Fr::one());
+  ok &= (s1.v[0] == 1);
+  for (int i = 1; i < 8; ++i) ok &= (s1.v[i] == 0);
+  u256 x = one, y = Fp::dbl(one);
+  u256 three = Fp::add(Fp::dbl(one), one);
+  ok &= Fp::eq(Fp::sqr(y), Fp::add(Fp::mul(Fp::sqr(x), x), three));
+  // 5*G via madd chain == to_affine(dbl(dbl(G)) + G)
+  g1_aff g{x, y};
+  g1_acc a = G1::acc_inf();
+  for (int i = 0; i < 5; ++i) G1::madd(a, g);
+  g1_acc b = G1::dbl(G1::dbl(G1::from_affine(g)));
+  G1::madd(b, g);
+  g1_aff pa = G1::to_affine(a), pb = G1::to_affine(b);
+  ok &= Fp::eq(pa.x, pb.x) && Fp::eq(pa.y, pb.y);
+  // inverse
+  ok &= Fp::eq(Fp::mul(three, Fp::inv(three)), one);
+  out[0] = ok;
+}
+
+extern "C" int32_t g16_selftest(g16_ctx* ctx) {
+  if (!ctx) return G16_EINVAL;
+  static_assert(sizeof(u256) == 32 && sizeof(g1_aff) == 64 && sizeof(g2_aff) == 128, "layout");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->stage_o, 512))) return rc;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, (uint32_t*)ctx->stage_o.p);
+  uint32_t ok = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&ok, ctx->stage_o.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ok != 1) {
+    ctx->err = "device arithmetic self-test failed";
+    return G16_ESELFTEST;
+  }
+  return G16_OK;
+}

@@ -1,0 +1,376 @@
+// Pippenger multi-scalar multiplication kernels for CDNA4 (G1 and G2 share the templates).
+// Replaces the hot loop behind msmConstantineG1/G2 (reference groth16/bn128/msm.nim:35-83, i.e.
+// constantine's multiScalarMul_vartime) -- same inputs (Fr scalars, affine points, (0,0) = inf),
+// same canonical affine output.
+//
+// Pipeline (one stream, no host round trip inside):
+//   K1 msm_count     scalar -> signed c-bit digits; histogram of (window,|digit|) buckets   [HBM: 32 B/scalar]
+//   K2 scan3         exclusive scans: bucket offsets + extra-segment offsets + heavy list
+//   K3 msm_scatter   recompute digits, write (point index | sign) into its bucket's slot
+//   K4 msm_accum     one thread per bucket *segment* (<= L entries): XYZZ += affine (8M+2S each)
+//   K5 msm_heavy     one workgroup per bucket that was split in >1 segment: LDS tree of partials
+//   K6 msm_reduce1/2 sum_k k*B_k per window: chunked running sums, then LDS suffix-scan per window
+//   K7 msm_fold      sum_w 2^(cw) S_w (or plain sum for precomputed tables) + one inversion -> affine
+//
+// Load balance: work is cut by *entries*, not by buckets -- a circom witness puts ~30 % of all
+// scalars in bucket (w=0, d=1); that bucket becomes ~N/L segments handled by N/L threads.
+#pragma once
+#include "ec.cuh"
+
+namespace g16 {
+
+constexpr int MSM_BLOCK = 256;
+constexpr int FR_BITS = 254;
+
+struct MsmParams {
+  uint32_t n;            // number of (scalar, point) pairs
+  uint32_t c;            // window bits
+  uint32_t nwin;         // number of windows  = FR_BITS / c + 1
+  uint32_t nbuckets;     // nwin << (c-1)  (or 1 << (c-1) when tables fold all windows into one set)
+  uint32_t seg;          // L: max entries per accumulate task
+  uint32_t scalars_mont; // 1: scalars are Montgomery Fr limbs (Nim seq[Fr]); 0: canonical LE (.wtns)
+  uint32_t tables;       // 1: points array holds nwin tables [w][i] = 2^(c w) P_i ; single bucket set
+  uint32_t max_extra;    // capacity of the extra-segment list
+};
+
+// canonical scalar limbs into LDS (layout [limb][thread]: conflict-free), then signed digits
+template <class EMIT>
+__device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, uint32_t i, const MsmParams& P,
+                                           uint32_t* lds_limbs, EMIT&& emit) {
+  u256 s = scalars[i];
+  if (P.scalars_mont) s = Fr::from_mont(s);
+  if (Fr::is_zero(s)) return;
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lds_limbs[j * MSM_BLOCK + tid] = s.v[j];
+  lds_limbs[8 * MSM_BLOCK + tid] = 0;
+  const uint32_t c = P.c, half = 1u << (c - 1), mask = (1u << c) - 1;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < P.nwin; ++w) {
+    uint32_t bit = w * c, idx = bit >> 5, sh = bit & 31;
+    uint64_t two = (uint64_t)lds_limbs[idx * MSM_BLOCK + tid] |
+                   ((uint64_t)lds_limbs[(idx + 1) * MSM_BLOCK + tid] << 32);
+    uint32_t raw = ((uint32_t)(two >> sh) & mask) + carry;
+    uint32_t neg = raw > half ? 1u : 0u;
+    uint32_t mag = neg ? (1u << c) - raw : raw;
+    carry = neg;
+    if (mag) emit(w, mag - 1, neg);
+  }
+}
+
+static __global__ void __launch_bounds__(MSM_BLOCK) msm_count(const u256* __restrict__ scalars, MsmParams P,
+                                                       uint32_t* __restrict__ count) {
+  __shared__ uint32_t limbs[9 * MSM_BLOCK];
+  uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  if (i >= P.n) return;
+  const uint32_t bshift = P.tables ? 0 : (P.c - 1);
+  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t) {
+    atomicAdd(&count[(P.tables ? 0u : (w << bshift)) + k], 1u);
+  });
+}
+
+static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __restrict__ scalars, MsmParams P,
+                                                         const uint32_t* __restrict__ offset,
+                                                         uint32_t* __restrict__ cursor,
+                                                         uint32_t* __restrict__ entries) {
+  __shared__ uint32_t limbs[9 * MSM_BLOCK];
+  uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  if (i >= P.n) return;
+  const uint32_t bshift = P.tables ? 0 : (P.c - 1);
+  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t neg) {
+    uint32_t b = (P.tables ? 0u : (w << bshift)) + k;
+    uint32_t pos = offset[b] + atomicAdd(&cursor[b], 1u);
+    // entry = point index (table-major when tables are used) | sign in bit 31
+    uint32_t pidx = P.tables ? (w * P.n + i) : i;
+    entries[pos] = pidx | (neg << 31);
+  });
+}
+
+// ---- three-phase exclusive scan over the bucket histogram ------------------------------------------
+// produces offset[b] = sum_{b'<b} count[b'], xoff[b] = sum_{b'<b} extra(b') with
+// extra(b) = max(ceil(count/L) - 1, 0), and appends buckets with extra(b) > 0 to the heavy list.
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;                       // per thread
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;  // 2048 buckets per workgroup
+
+__device__ __forceinline__ uint32_t extra_segs(uint32_t cnt, uint32_t L) { return cnt > L ? (cnt - 1) / L : 0u; }
+
+__device__ __forceinline__ uint2 block_excl_scan2(uint2 v, uint2* total) {
+  // exclusive scan of (x,y) across SCAN_BLOCK threads: wave shuffles + LDS across the 4 waves
+  __shared__ uint2 wsum[SCAN_BLOCK / 64];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint2 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t x = __shfl_up(inc.x, d, 64), y = __shfl_up(inc.y, d, 64);
+    if (lane >= (uint32_t)d) { inc.x += x; inc.y += y; }
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint2 base = make_uint2(0, 0), tot = make_uint2(0, 0);
+#pragma unroll
+  for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+    uint2 s = wsum[w];
+    if ((uint32_t)w < wave) { base.x += s.x; base.y += s.y; }
+    tot.x += s.x; tot.y += s.y;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return make_uint2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+}
+
+static __global__ void __launch_bounds__(SCAN_BLOCK) scan_tile_sums(const uint32_t* __restrict__ count, uint32_t nb,
+                                                             uint32_t L, uint2* __restrict__ tile_sum) {
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint2 s = make_uint2(0, 0);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    uint32_t b = base + j;
+    uint32_t cnt = b < nb ? count[b] : 0u;
+    s.x += cnt;
+    s.y += extra_segs(cnt, L);
+  }
+  uint2 tot;
+  block_excl_scan2(s, &tot);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+// single workgroup: exclusive scan of the tile sums in place; totals -> info[0..1]
+static __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles(uint2* __restrict__ tile_sum, uint32_t ntiles,
+                                                         uint32_t* __restrict__ info) {
+  uint2 carry = make_uint2(0, 0);
+  for (uint32_t base = 0; base < ntiles; base += SCAN_BLOCK) {
+    uint32_t t = base + threadIdx.x;
+    uint2 v = t < ntiles ? tile_sum[t] : make_uint2(0, 0);
+    uint2 tot;
+    uint2 ex = block_excl_scan2(v, &tot);
+    if (t < ntiles) tile_sum[t] = make_uint2(ex.x + carry.x, ex.y + carry.y);
+    carry.x += tot.x;
+    carry.y += tot.y;
+  }
+  if (threadIdx.x == 0) {
+    info[0] = carry.x;  // total entries
+    info[1] = carry.y;  // total extra segments
+  }
+}
+static __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply(const uint32_t* __restrict__ count, uint32_t nb, uint32_t L,
+                                                         const uint2* __restrict__ tile_sum,
+                                                         uint32_t* __restrict__ offset, uint32_t* __restrict__ xoff,
+                                                         uint32_t* __restrict__ heavy, uint32_t* __restrict__ info) {
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t cnt[SCAN_ITEMS];
+  uint2 s = make_uint2(0, 0);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    uint32_t b = base + j;
+    cnt[j] = b < nb ? count[b] : 0u;
+    s.x += cnt[j];
+    s.y += extra_segs(cnt[j], L);
+  }
+  uint2 ex = block_excl_scan2(s, nullptr);
+  uint2 t0 = tile_sum[blockIdx.x];
+  uint32_t o = t0.x + ex.x, x = t0.y + ex.y;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    uint32_t b = base + j;
+    if (b < nb) {
+      offset[b] = o;
+      xoff[b] = x;
+      uint32_t e = extra_segs(cnt[j], L);
+      if (e) heavy[atomicAdd(&info[2], 1u)] = b;
+      o += cnt[j];
+      x += e;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) offset[nb] = o;
+}
+
+// extra-segment descriptors: xseg[xoff[b] + s - 1] = (b, s) for s = 1..extra(b)
+static __global__ void __launch_bounds__(MSM_BLOCK) msm_make_extra(const uint32_t* __restrict__ heavy,
+                                                            const uint32_t* __restrict__ info,
+                                                            const uint32_t* __restrict__ offset,
+                                                            const uint32_t* __restrict__ xoff, uint32_t L,
+                                                            uint32_t max_extra, uint2* __restrict__ xseg) {
+  // one workgroup per heavy bucket (grid-stride), threads stride over its segments
+  const uint32_t nheavy = info[2];
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    uint32_t b = heavy[h];
+    uint32_t cnt = offset[b + 1] - offset[b];
+    uint32_t e = extra_segs(cnt, L), x0 = xoff[b];
+    for (uint32_t s = threadIdx.x; s < e; s += MSM_BLOCK)
+      if (x0 + s < max_extra) xseg[x0 + s] = make_uint2(b, s + 1);
+  }
+}
+
+// ---- K4: bucket-segment accumulation -----------------------------------------------------------
+template <class C>
+__device__ __forceinline__ typename C::Aff load_point(const typename C::Aff* __restrict__ pts, uint32_t e) {
+  typename C::Aff p = pts[e & 0x7fffffffu];
+  if (e >> 31) p = C::neg(p);
+  return p;
+}
+
+template <class C>
+__global__ void __launch_bounds__(MSM_BLOCK) msm_accum(const typename C::Aff* __restrict__ points,
+                                                       const uint32_t* __restrict__ entries,
+                                                       const uint32_t* __restrict__ offset,
+                                                       const uint2* __restrict__ xseg,
+                                                       const uint32_t* __restrict__ info, MsmParams P,
+                                                       typename C::Acc* __restrict__ partial) {
+  uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  uint32_t b, s;
+  if (t < P.nbuckets) {
+    b = t;
+    s = 0;
+  } else {
+    uint32_t x = t - P.nbuckets;
+    uint32_t nx = info[1] < P.max_extra ? info[1] : P.max_extra;
+    if (x >= nx) return;
+    uint2 d = xseg[x];
+    b = d.x;
+    s = d.y;
+  }
+  uint32_t beg = offset[b], end = offset[b + 1];
+  beg += s * P.seg;
+  if (end > beg + P.seg) end = beg + P.seg;
+  typename C::Acc acc = C::acc_inf();
+  for (uint32_t j = beg; j < end; ++j) C::madd(acc, load_point<C>(points, entries[j]));
+  partial[t] = acc;
+}
+
+// ---- K5: combine the segments of split buckets (one workgroup per heavy bucket) ---------------------
+template <class C, int BLOCK>
+__device__ __forceinline__ typename C::Acc block_sum(typename C::Acc v, typename C::Acc* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll 1
+  for (int stride = BLOCK / 2; stride > 0; stride >>= 1) {
+    if ((int)threadIdx.x < stride) {
+      typename C::Acc a = sh[threadIdx.x];
+      C::add(a, sh[threadIdx.x + stride]);
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  typename C::Acc r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+constexpr int HEAVY_BLOCK = 256;
+template <class C>
+__global__ void __launch_bounds__(HEAVY_BLOCK) msm_heavy(const uint32_t* __restrict__ heavy,
+                                                         const uint32_t* __restrict__ info,
+                                                         const uint32_t* __restrict__ offset,
+                                                         const uint32_t* __restrict__ xoff, MsmParams P,
+                                                         typename C::Acc* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
+  const uint32_t nheavy = info[2];
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    uint32_t b = heavy[h];
+    uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
+    typename C::Acc acc = C::acc_inf();
+    // segment 0 lives at partial[b]; segments 1..e at partial[nbuckets + x0 + s - 1]
+    for (uint32_t s = threadIdx.x; s <= e; s += HEAVY_BLOCK) {
+      uint32_t idx = s == 0 ? b : P.nbuckets + x0 + s - 1;
+      C::add(acc, partial[idx]);
+    }
+    typename C::Acc r = block_sum<C, HEAVY_BLOCK>(acc, sh);
+    if (threadIdx.x == 0) partial[b] = r;
+  }
+}
+
+// ---- K6: bucket reduction  S_w = sum_{k=1}^{K} k * B_{w,k},  K = 2^(c-1) -----------------------------
+// stage 1: thread per chunk of RC consecutive buckets: R_j = sum B_k, A_j = sum (k - j*RC) B_k
+constexpr int RED_CHUNK = 16;
+template <class C>
+__global__ void __launch_bounds__(MSM_BLOCK) msm_reduce1(const typename C::Acc* __restrict__ partial,
+                                                         const uint32_t* __restrict__ offset, uint32_t nbuckets,
+                                                         typename C::Acc* __restrict__ chunkR,
+                                                         typename C::Acc* __restrict__ chunkA) {
+  uint32_t j = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  uint32_t b0 = j * RED_CHUNK;
+  if (b0 >= nbuckets) return;
+  typename C::Acc run = C::acc_inf(), acc = C::acc_inf();
+  for (int k = RED_CHUNK - 1; k >= 0; --k) {
+    uint32_t b = b0 + k;
+    if (b < nbuckets && offset[b + 1] != offset[b]) C::add(run, partial[b]);
+    C::add(acc, run);
+  }
+  chunkR[j] = run;
+  chunkA[j] = acc;
+}
+// stage 2: one workgroup per window over its M = K/RC chunks (index m = 0..M-1, bucket k = m*RC + 1 + i):
+//   S_w = sum_m A_m + RC * sum_m m * R_m ,   sum_m m R_m = sum_{m>=1} suffix(m)
+// done with a Hillis-Steele suffix scan + tree sums in LDS.  M may exceed the block: threads loop.
+constexpr int RED2_BLOCK = 256;
+template <class C>
+__global__ void __launch_bounds__(RED2_BLOCK) msm_reduce2(const typename C::Acc* __restrict__ chunkR,
+                                                          const typename C::Acc* __restrict__ chunkA,
+                                                          uint32_t chunks_per_window,
+                                                          typename C::Acc* __restrict__ window_sum) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
+  const uint32_t w = blockIdx.x, M = chunks_per_window;
+  const typename C::Acc* R = chunkR + (size_t)w * M;
+  const typename C::Acc* A = chunkA + (size_t)w * M;
+  // Each thread owns a contiguous slice of chunk indices [lo, hi): running sums inside the slice,
+  // then a block-level suffix scan of the slice totals.
+  const uint32_t per = (M + RED2_BLOCK - 1) / RED2_BLOCK;
+  const uint32_t lo = threadIdx.x * per, hi = (lo + per < M) ? lo + per : M;
+  typename C::Acc sumA = C::acc_inf(), run = C::acc_inf(), wsum = C::acc_inf();
+  // local: run = sum_{m in slice} R_m ; wsum = sum_{m in slice} (m - lo) R_m   (descending running sum)
+  if (lo < M) {
+    for (uint32_t m = hi; m-- > lo;) {
+      C::add(wsum, run);      // wsum += sum_{m' > m} R_m'   -> each R_m' counted (m' - m) times; ends at m = lo
+      C::add(run, R[m]);
+      C::add(sumA, A[m]);
+    }
+  }
+  // block suffix scan (exclusive) of slice totals `run`:  above_t = sum_{t' > t} run_t'
+  sh[threadIdx.x] = run;
+  __syncthreads();
+  typename C::Acc incl = run;
+#pragma unroll 1
+  for (int d = 1; d < RED2_BLOCK; d <<= 1) {
+    typename C::Acc other = C::acc_inf();
+    bool has = (int)threadIdx.x + d < RED2_BLOCK;
+    if (has) other = sh[threadIdx.x + d];
+    __syncthreads();
+    if (has) C::add(incl, other);
+    sh[threadIdx.x] = incl;
+    __syncthreads();
+  }
+  // sum_m m R_m = sum_t [ wsum_t + lo_t * run_t ]  with  lo_t * run_t summed as: each slice total is
+  // counted once for every chunk index below its slice start.  Using suffix sums:
+  //   sum_t lo_t run_t = per * sum_{t>=1} suffix_incl(t)        (lo_t = t * per)
+  typename C::Acc suf = (threadIdx.x >= 1 && lo < M) ? incl : C::acc_inf();
+  __syncthreads();
+  typename C::Acc sufsum = block_sum<C, RED2_BLOCK>(suf, sh);
+  typename C::Acc wtot = block_sum<C, RED2_BLOCK>(wsum, sh);
+  typename C::Acc atot = block_sum<C, RED2_BLOCK>(sumA, sh);
+  if (threadIdx.x == 0) {
+    typename C::Acc t = C::mul_small(sufsum, per);  // per * sum suffix
+    C::add(t, wtot);                                // = sum_m m R_m
+    t = C::mul_small(t, RED_CHUNK);                 // * RC
+    C::add(t, atot);
+    window_sum[w] = t;
+  }
+}
+
+// ---- K7: fold windows (Horner) + canonical affine ----------------------------------------------------
+template <class C>
+__global__ void msm_fold(const typename C::Acc* __restrict__ window_sum, uint32_t nwin, uint32_t c,
+                         typename C::Aff* __restrict__ out_aff, typename C::Acc* __restrict__ out_acc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  typename C::Acc r = C::acc_inf();
+  for (int w = (int)nwin - 1; w >= 0; --w) {
+    if (!C::is_inf(r))
+      for (uint32_t i = 0; i < c; ++i) r = C::dbl(r);
+    C::add(r, window_sum[w]);
+  }
+  if (out_acc) *out_acc = r;
+  if (out_aff) *out_aff = C::to_affine(r);
+}
+
+}  // namespace g16

@@ -1,0 +1,122 @@
+// Radix-2 NTT over BN254 Fr for CDNA4.  Replaces forwardNTT / inverseNTT of the reference
+// (groth16/math/ntt.nim:17-161): natural order in and out, forward unscaled
+// y_k = sum_i x_i w^(ik), inverse scaled by 1/n, w = gen28^(2^(28-log2 n)) (math/domain.nim:26-33).
+//
+// The reference recursion is replaced by a Stockham auto-sort decomposition in <= 4 passes; every pass
+// performs up to 8 radix-2 DIF butterfly stages of a size-R sub-transform inside LDS:
+//   pass with stride s (product of earlier radices), l = n / (s R):
+//     for base = k + s*j  (k < s, j < l):   Z_q = sum_r x[base + (n/R) r] w_R^(r q)      (LDS butterflies)
+//                                           y[k + s (R j + q)] = Z_q * w_n^(s j q)        (inter-pass twiddle)
+// A workgroup owns B consecutive bases, so global reads/writes are B*32-byte contiguous segments.
+// HBM traffic: 64 B per element per pass (algorithmic minimum for one pass: 64 B/element).
+#pragma once
+#include "ff.cuh"
+
+namespace g16 {
+
+// gen28 (math/domain.nim:26), standard form 0x2a3c09f0a58a7e85...9bd61b6e725b19f0, little-endian limbs
+__device__ __forceinline__ u256 ntt_gen28() {
+  u256 g;
+  g.v[0] = 0x725b19f0u; g.v[1] = 0x9bd61b6eu; g.v[2] = 0x41112ed4u; g.v[3] = 0x402d111eu;
+  g.v[4] = 0x8ef62abcu; g.v[5] = 0x00e0a7ebu; g.v[6] = 0xa58a7e85u; g.v[7] = 0x2a3c09f0u;
+  return Fr::to_mont(g);
+}
+__device__ __forceinline__ u256 ntt_omega(uint32_t log2n) {
+  u256 w = ntt_gen28();
+  for (uint32_t i = log2n; i < 28; ++i) w = Fr::sqr(w);
+  return w;
+}
+__device__ __forceinline__ u256 fr_pow_u32(u256 b, uint32_t e) {
+  u256 r = Fr::one();
+  while (e) {
+    if (e & 1) r = Fr::mul(r, b);
+    b = Fr::sqr(b);
+    e >>= 1;
+  }
+  return r;
+}
+
+// tw[i] = w^i for i < n/2 ;  tw[n/2] = 1/n   (both Montgomery).  One table serves both directions:
+// w^(-e) = w^(n-e) and w^(e) = -w^(e-n/2) for e >= n/2.
+static __global__ void __launch_bounds__(256) ntt_make_twiddles(u256* __restrict__ tw, uint32_t log2n) {
+  const uint32_t half = log2n ? (1u << (log2n - 1)) : 0u;
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < half) {
+    tw[i] = fr_pow_u32(ntt_omega(log2n), i);
+  } else if (i == half) {
+    // 1/n = (1/2)^log2n : div2 applied to one  (ntt.nim folds the same halving into every level)
+    u256 h = Fr::one();
+    for (uint32_t k = 0; k < log2n; ++k) h = Fr::div2(h);
+    tw[half] = h;
+  }
+}
+
+// w^(+-e), e in [0, n)
+__device__ __forceinline__ u256 ntt_tw(const u256* __restrict__ tw, uint32_t e, uint32_t log2n, int inverse) {
+  const uint32_t n = 1u << log2n, half = n >> 1;
+  if (inverse && e) e = n - e;
+  if (e < half) return tw[e];
+  return Fr::neg(tw[e - half]);
+}
+
+constexpr int NTT_BLOCK = 256;
+constexpr int NTT_TILE = 2048;  // elements per workgroup tile (64 KB of LDS)
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return __brev(x) >> (32 - bits); }
+
+// one pass: rho radix-2 stages of B sub-transforms of size R = 2^rho per workgroup
+static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restrict__ x, u256* __restrict__ y,
+                                                      const u256* __restrict__ tw, uint32_t log2n, uint32_t log2s,
+                                                      uint32_t rho, uint32_t log2b, int inverse, int last) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u256* lds = reinterpret_cast<u256*>(smem);
+  const uint32_t R = 1u << rho, B = 1u << log2b;
+  const uint32_t nR = 1u << (log2n - rho);  // n / R = number of bases = input stride between r's
+  const uint32_t base0 = blockIdx.x << log2b;
+  const uint32_t tile = R << log2b;
+  const uint32_t tid = threadIdx.x;
+
+  // load: element (r, b) <- x[base0 + b + nR * r]   (LDS index r*B + b)
+  for (uint32_t e = tid; e < tile; e += NTT_BLOCK) {
+    uint32_t b = e & (B - 1), r = e >> log2b;
+    lds[e] = x[(size_t)base0 + b + (size_t)nR * r];
+  }
+  __syncthreads();
+
+  // rho DIF stages: half distance h = R/2 ... 1 ; twiddle w_(2h)^p = w_n^(p * n/(2h))
+  for (uint32_t lh = rho; lh-- > 0;) {
+    const uint32_t h = 1u << lh;
+    for (uint32_t bf = tid; bf < (tile >> 1); bf += NTT_BLOCK) {
+      uint32_t b = bf & (B - 1), pi = bf >> log2b;
+      uint32_t p = pi & (h - 1);
+      uint32_t i = ((pi >> lh) << (lh + 1)) | p;
+      uint32_t ia = (i << log2b) | b, ib = ((i + h) << log2b) | b;
+      u256 a = lds[ia], c = lds[ib];
+      u256 sum = Fr::add(a, c), dif = Fr::sub(a, c);
+      if (p) dif = Fr::mul(dif, ntt_tw(tw, p << (log2n - lh - 1), log2n, inverse));  // p == 0: twiddle 1
+      lds[ia] = sum;
+      lds[ib] = dif;
+    }
+    __syncthreads();
+  }
+
+  // store: Z_q (at LDS row bitrev(q)) * w^(s j q)  ->  y[k + s (R j + q)]
+  const uint32_t s_mask = (1u << log2s) - 1;
+  for (uint32_t e = tid; e < tile; e += NTT_BLOCK) {
+    uint32_t b = e & (B - 1), q = e >> log2b;
+    uint32_t base = base0 + b;
+    uint32_t k = base & s_mask, j = base >> log2s;
+    u256 v = lds[(bitrev(q, rho) << log2b) | b];
+    if (!last) {
+      // exponent s*j*q < n ; computed mod n in 64 bits
+      uint64_t ex = ((uint64_t)j * q) << log2s;
+      uint32_t em = (uint32_t)(ex & ((1ull << log2n) - 1));
+      if (em) v = Fr::mul(v, ntt_tw(tw, em, log2n, inverse));
+    } else if (inverse) {
+      v = Fr::mul(v, tw[(1u << log2n) >> 1]);  // * 1/n
+    }
+    y[(size_t)k + ((size_t)(((size_t)j << rho) + q) << log2s)] = v;
+  }
+}
+
+}  // namespace g16

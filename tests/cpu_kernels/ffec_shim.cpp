@@ -1,0 +1,73 @@
+// Test-only: compiles the *device* field/curve headers with g++ so their formulas can be checked
+// against the oracle on a machine without a GPU.  Not part of the product library.
+#include "../../nim_groth16_amd/csrc/ec.cuh"
+#include <cstring>
+using namespace g16;
+
+template <class T> static T ld(const void* p) { T t; std::memcpy(&t, p, sizeof(T)); return t; }
+template <class T> static void st(void* p, const T& t) { std::memcpy(p, &t, sizeof(T)); }
+
+extern "C" {
+// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 dbl 6 div2 7 inv 8 from_mont 9 to_mont ; field: 0 Fp 1 Fr
+void shim_field_op(int field, int op, const void* a, const void* b, void* r) {
+  u256 x = ld<u256>(a), y = ld<u256>(b), z;
+  auto run = [&](auto F) {
+    using FF = decltype(F);
+    switch (op) {
+      case 0: z = FF::add(x, y); break;
+      case 1: z = FF::sub(x, y); break;
+      case 2: z = FF::mul(x, y); break;
+      case 3: z = FF::sqr(x); break;
+      case 4: z = FF::neg(x); break;
+      case 5: z = FF::dbl(x); break;
+      case 6: z = FF::div2(x); break;
+      case 7: z = FF::inv(x); break;
+      case 8: z = FF::from_mont(x); break;
+      default: z = FF::to_mont(x); break;
+    }
+  };
+  if (field == 0) run(Fp{}); else run(Fr{});
+  st(r, z);
+}
+// op: 0 add 1 sub 2 mul 3 sqr 4 neg 7 inv
+void shim_fp2_op(int op, const void* a, const void* b, void* r) {
+  fp2_t x = ld<fp2_t>(a), y = ld<fp2_t>(b), z;
+  switch (op) {
+    case 0: z = Fp2::add(x, y); break;
+    case 1: z = Fp2::sub(x, y); break;
+    case 2: z = Fp2::mul(x, y); break;
+    case 3: z = Fp2::sqr(x); break;
+    case 4: z = Fp2::neg(x); break;
+    default: z = Fp2::inv(x); break;
+  }
+  st(r, z);
+}
+// sums n affine points with madd (op 0), or with XYZZ+XYZZ add of from_affine (op 1), or as
+// k*P via mul_small on the first point (op 2, k = n); returns the canonical affine result
+void shim_g1_sum(int op, const void* pts, int n, void* out) {
+  g1_acc acc = G1::acc_inf();
+  const char* p = (const char*)pts;
+  if (op == 2) {
+    acc = G1::mul_small(G1::from_affine(ld<g1_aff>(p)), (uint32_t)n);
+  } else {
+    for (int i = 0; i < n; ++i) {
+      g1_aff q = ld<g1_aff>(p + 64 * i);
+      if (op == 0) G1::madd(acc, q); else G1::add(acc, G1::from_affine(q));
+    }
+  }
+  st(out, G1::to_affine(acc));
+}
+void shim_g2_sum(int op, const void* pts, int n, void* out) {
+  g2_acc acc = G2::acc_inf();
+  const char* p = (const char*)pts;
+  if (op == 2) {
+    acc = G2::mul_small(G2::from_affine(ld<g2_aff>(p)), (uint32_t)n);
+  } else {
+    for (int i = 0; i < n; ++i) {
+      g2_aff q = ld<g2_aff>(p + 128 * i);
+      if (op == 0) G2::madd(acc, q); else G2::add(acc, G2::from_affine(q));
+    }
+  }
+  st(out, G2::to_affine(acc));
+}
+}

@@ -1,0 +1,96 @@
+"""GPU parity: HIP MSM (through the C ABI) == oracle, bit-exact on the canonical affine encoding.
+Mirrors what the reference can check about msmMultiThreadedG1/G2 (groth16/bn128/msm.nim:89-158)."""
+import pytest
+
+from oracle import bn254_ref as o
+from tests import inputs as I
+
+pytestmark = pytest.mark.gpu
+
+PSZ = {1: 64, 2: 128}
+GEN = {1: o.g1_to_bytes(o.GEN1), 2: o.g2_to_bytes(o.GEN2)}
+INF = {1: bytes(64), 2: bytes(128)}
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 63, 127, 128, 1000])
+def test_msm_small_vs_naive_definition(ctx, orc, group, n):
+    ks, pts = I.points_with_logs(orc, group, n, seed=100 + n)
+    sc = I.uniform_scalars(n, seed=200 + n)
+    sb = I.fr_mont_bytes(sc)
+    got = ctx.msm(group, sb, pts, n)
+    assert got == orc.msm_naive(group, sb, pts)          # msm.nim:162-198 definition
+    assert got == I.expected_from_logs(group, sc, ks)    # closed form
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_empty_is_infinity(ctx, group):
+    assert ctx.msm(group, b"", b"", 0) == INF[group]      # msm.nim:117 res = infG1
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_edge_scalars_and_points(ctx, orc, group):
+    psz = PSZ[group]
+    ks, pts = I.points_with_logs(orc, group, 8, seed=7)
+    P = [pts[psz * i:psz * (i + 1)] for i in range(8)]
+    C = o.G1 if group == 1 else o.G2
+    dec = o.g1_from_bytes if group == 1 else o.g2_from_bytes
+    enc = o.g1_to_bytes if group == 1 else o.g2_to_bytes
+    negP0 = enc(C.neg(dec(P[0])))
+    cases = {
+        "all zero scalars": ([0] * 8, P),
+        "scalar one": ([1] * 8, P),
+        "scalar r-1": ([o.R - 1] * 8, P),
+        "repeated point": ([5, 5, 5, 9], [P[0], P[0], P[0], P[1]]),
+        "P and -P same bucket": ([77, 77, 3], [P[0], negP0, P[2]]),
+        "infinity inputs": ([11, 12, 13], [INF[group], P[1], INF[group]]),
+        "cancels to infinity": ([9, 9], [P[0], negP0]),
+        "half window edge": ([1 << 15, (1 << 15) + 1, (1 << 16) - 1, 1 << 16], P[:4]),
+        "doubling inside bucket": ([3, 3], [P[4], P[4]]),
+    }
+    for name, (sc, pl) in cases.items():
+        sb, pb = I.fr_mont_bytes(sc), b"".join(pl)
+        assert ctx.msm(group, sb, pb, len(sc)) == orc.msm_naive(group, sb, pb), name
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_std_scalars_flag(ctx, orc, group):
+    n = 300
+    ks, pts = I.points_with_logs(orc, group, n, seed=31)
+    sc = I.uniform_scalars(n, seed=32)
+    assert ctx.msm(group, I.fr_std_bytes(sc), pts, n, mont=False) == I.expected_from_logs(group, sc, ks)
+
+
+@pytest.mark.parametrize("group,n", [(1, 1 << 14), (2, 1 << 13)])
+@pytest.mark.parametrize("dist", ["uniform", "circom"])
+def test_msm_mid_vs_oracle_pippenger(ctx, orc, group, n, dist):
+    ks, pts = I.points_with_logs(orc, group, n, seed=41)
+    sc = I.uniform_scalars(n, 42) if dist == "uniform" else I.circom_like_scalars(n, 43)
+    sb = I.fr_mont_bytes(sc)
+    got = ctx.msm(group, sb, pts, n)
+    assert got == orc.msm(group, sb, pts)
+    assert got == I.expected_from_logs(group, sc, ks)
+
+
+def test_msm_skewed_single_bucket(ctx, orc):
+    """every scalar equal: one bucket per window holds all N entries (heavy-bucket path)."""
+    n = 20000
+    ks, pts = I.points_with_logs(orc, 1, n, seed=51)
+    sc = [0x1234567] * n
+    assert ctx.msm(1, I.fr_mont_bytes(sc), pts, n) == I.expected_from_logs(1, sc, ks)
+
+
+def test_msm_partials_sum(ctx, orc):
+    """msm.nim:105-119: contiguous chunks, partials added -> same point (multi-GPU sharding path)."""
+    import torch
+    n = 3000
+    ks, pts = I.points_with_logs(orc, 1, n, seed=61)
+    sc = I.uniform_scalars(n, 62)
+    sb = I.fr_mont_bytes(sc)
+    full = ctx.msm(1, sb, pts, n)
+    parts = b""
+    for a, b in ((0, 1000), (1000, 1001), (1001, 3000)):
+        ds = torch.frombuffer(bytearray(sb[32 * a:32 * b]), dtype=torch.uint8).cuda()
+        dp = torch.frombuffer(bytearray(pts[64 * a:64 * b]), dtype=torch.uint8).cuda()
+        parts += ctx.msm(1, ds.data_ptr(), dp.data_ptr(), b - a, partial=True)
+    assert ctx.sum_partials(1, parts, 3) == full
