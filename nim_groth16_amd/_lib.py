@@ -41,6 +41,12 @@ def load_library():
     if not os.path.exists(path):
         raise G16Error(G16_ENODEV, f"{path} not found: build it with `make -C nim_groth16_amd/csrc` "
                                    "(or __graft_entry__.build()); there is no CPU fallback")
+    # torch bundles its own libamdhip64.so.7; load it first so that this library binds to the SAME HIP
+    # runtime (same SONAME) -- two HIP runtimes in one process cannot both own the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     vp, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_size_t
     lib.g16_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
