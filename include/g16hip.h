@@ -44,6 +44,8 @@ typedef struct g16_points g16_points; /* device-resident point set (ProverPoints
 /* flags for the scalar argument of the MSM calls */
 #define G16_SCALARS_MONT 1u /* Nim seq[Fr] limbs (Montgomery) -- what msm.nim:42-44 `toBig` consumes   */
 #define G16_SCALARS_STD 0u  /* canonical little-endian (raw .wtns values)                              */
+#define G16_SCALARS_DEVICE 2u /* g16_msm_points only: the scalar pointer is a device (HBM) pointer       */
+#define G16_OUT_PARTIAL 4u    /* g16_msm_points only: write the 128/256-byte XYZZ partial, not the affine */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int32_t g16_ctx_create(int32_t device, g16_ctx** out);
@@ -78,6 +80,22 @@ int32_t g16_msm_g2_partial_dev(g16_ctx* ctx, const void* d_scalars, uint32_t sca
  * `res += sync pending[k]` loop (msm.nim:117-119, 151-153) */
 int32_t g16_g1_sum_partials(g16_ctx* ctx, const void* xyzz, size_t count, void* out_affine);
 int32_t g16_g2_sum_partials(g16_ctx* ctx, const void* xyzz, size_t count, void* out_affine);
+
+/* ---- registered point sets -------------------------------------------------------------------------
+ * The five ProverPoints arrays (pointsA1/B1/B2/C1/H1, groth16/zkey_types.nim:36-41) are constant per
+ * circuit and are loaded once (files/zkey.nim:201-224).  Registering a set copies it to HBM and
+ * precomputes the window tables 2^(c w) * P_i, so that no MSM against it contains a doubling chain.
+ * HBM cost: (254/c + 1) x the point set (c = 16 for n >= 2^20: 1 GiB per 2^20 G1 points). */
+int32_t g16_points_register_g1(g16_ctx* ctx, const void* points, size_t n, g16_points** out);
+int32_t g16_points_register_g2(g16_ctx* ctx, const void* points, size_t n, g16_points** out);
+int32_t g16_points_register_g1_dev(g16_ctx* ctx, const void* d_points, size_t n, g16_points** out);
+int32_t g16_points_register_g2_dev(g16_ctx* ctx, const void* d_points, size_t n, g16_points** out);
+void g16_points_release(g16_points* pts);
+size_t g16_points_count(const g16_points* pts);
+/* sum_i scalars[i] * P_i over the whole registered set (scalars: g16_points_count elements);
+ * flags = G16_SCALARS_MONT/STD | G16_SCALARS_DEVICE | G16_OUT_PARTIAL.  This is the call a prover makes
+ * per proof for msmMultiThreadedG1/G2 (groth16/prover.nim:282,288,294,301,302). */
+int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const void* scalars, uint32_t flags, void* out);
 
 /* ---- NTT: replaces forwardNTT / inverseNTT (groth16/math/ntt.nim:55-77, 139-161) ------------------- */
 /* natural order in and out; forward unscaled, inverse includes 1/n; omega = gen28^(2^(28-log2n))

@@ -8,13 +8,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 G16_OK, G16_EINVAL, G16_ENODEV, G16_EHIP, G16_ENOMEM, G16_ESELFTEST = 0, -1, -2, -3, -4, -5
-SCALARS_MONT, SCALARS_STD = 1, 0
+SCALARS_MONT, SCALARS_STD, SCALARS_DEVICE, OUT_PARTIAL = 1, 0, 2, 4
 
 # every symbol include/g16hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_last_error", "g16_ctx_set_stream", "g16_ctx_synchronize",
     "g16_selftest", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
     "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
+    "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
+    "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_msm_points",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
 ]
 
@@ -62,13 +64,21 @@ def load_library():
         getattr(lib, name).argtypes = [vp, vp, u32, vp, sz, vp]
     for name in ("g16_g1_sum_partials", "g16_g2_sum_partials"):
         getattr(lib, name).argtypes = [vp, vp, sz, vp]
+    for name in ("g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
+                 "g16_points_register_g2_dev"):
+        getattr(lib, name).argtypes = [vp, vp, sz, ctypes.POINTER(vp)]
+    lib.g16_points_release.argtypes = [vp]
+    lib.g16_points_release.restype = None
+    lib.g16_points_count.argtypes = [vp]
+    lib.g16_points_count.restype = sz
+    lib.g16_msm_points.argtypes = [vp, vp, vp, u32, vp]
     lib.g16_ntt_fr.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_ntt_fr_dev.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_profile_enable.argtypes = [vp, i32]
     lib.g16_profile_reset.argtypes = [vp]
     lib.g16_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
     for name in SYMBOLS:
-        if name not in ("g16_ctx_destroy", "g16_last_error"):
+        if name not in ("g16_ctx_destroy", "g16_last_error", "g16_points_release", "g16_points_count"):
             getattr(lib, name).restype = i32
     _lib = lib
     return lib
@@ -140,6 +150,20 @@ class Context:
         self._check(fn(self._h, s, SCALARS_MONT if mont else SCALARS_STD, p, n, out))
         return out.raw
 
+    def register_points(self, group: int, points, n: int, device: bool = False) -> "PointSet":
+        h = ctypes.c_void_p()
+        name = f"g16_points_register_g{group}" + ("_dev" if device else "")
+        self._check(getattr(self._lib, name)(self._h, _buf(points) if n else None, n, ctypes.byref(h)))
+        return PointSet(self, h, group, n)
+
+    def msm_points(self, pts: "PointSet", scalars, mont: bool = True, device: bool = False,
+                   partial: bool = False) -> bytes:
+        psz = 64 if pts.group == 1 else 128
+        out = ctypes.create_string_buffer(2 * psz if partial else psz)
+        flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0) | (OUT_PARTIAL if partial else 0)
+        self._check(self._lib.g16_msm_points(self._h, pts._h, _buf(scalars) if pts.n else None, flags, out))
+        return out.raw
+
     def sum_partials(self, group: int, xyzz: bytes, count: int) -> bytes:
         psz = 64 if group == 1 else 128
         out = ctypes.create_string_buffer(psz)
@@ -168,6 +192,24 @@ class Context:
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self._lib.g16_profile_report(self._h, buf, len(buf)))
         return json.loads(buf.value.decode())
+
+
+class PointSet:
+    """Device-resident point set with precomputed window tables (g16_points)."""
+
+    def __init__(self, ctx: Context, handle, group: int, n: int):
+        self.ctx, self._h, self.group, self.n = ctx, handle, group, n
+
+    def release(self):
+        if self._h:
+            self.ctx._lib.g16_points_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 _default_ctx = None

@@ -96,10 +96,23 @@ struct ProfScope {
 
 
 // implemented in msm_g1.hip / msm_g2.hip / ntt.hip
+// table_c == 0: d_points = n affine points; table_c != 0: d_points = tables of a registered set
 int32_t g16_msm_device_g1(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
-                          void* d_out_aff, void* d_out_acc);
+                          void* d_out_aff, void* d_out_acc, uint32_t table_c);
 int32_t g16_msm_device_g2(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
-                          void* d_out_aff, void* d_out_acc);
+                          void* d_out_aff, void* d_out_acc, uint32_t table_c);
+int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
+int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
+uint32_t g16_pick_window_g1(size_t n);
+
+// device-resident point set with precomputed window tables
+struct g16_points {
+  g16_ctx* ctx = nullptr;
+  int group = 1;          // 1: G1 (64-byte points), 2: G2 (128-byte points)
+  size_t n = 0;
+  uint32_t c = 0, nwin = 0;
+  void* d_tables = nullptr;  // nwin * n affine points, table-major
+};
 int32_t g16_sum_partials_device_g1(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
 int32_t g16_sum_partials_device_g2(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse);

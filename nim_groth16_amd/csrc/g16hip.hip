@@ -139,8 +139,118 @@ static int32_t msm_entry(g16_ctx* ctx, const void* scalars, uint32_t flags, cons
   if ((rc = ensure(ctx, ctx->stage_o, 512))) return rc;
   auto* d_aff = partial ? nullptr : (typename C::Aff*)ctx->stage_o.p;
   auto* d_acc = partial ? (typename C::Acc*)ctx->stage_o.p : nullptr;
-  rc = sizeof(typename C::Aff) == 64 ? g16_msm_device_g1(ctx, d_s, flags, d_p, n, d_aff, d_acc)
-                                     : g16_msm_device_g2(ctx, d_s, flags, d_p, n, d_aff, d_acc);
+  rc = sizeof(typename C::Aff) == 64 ? g16_msm_device_g1(ctx, d_s, flags, d_p, n, d_aff, d_acc, 0)
+                                     : g16_msm_device_g2(ctx, d_s, flags, d_p, n, d_aff, d_acc, 0);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_o.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+
+// ---- registered point sets (ProverPoints are constant per circuit: zkey_types.nim:36-41) ----------------
+static int32_t points_register(g16_ctx* ctx, int group, const void* points, size_t n, bool on_device,
+                               g16_points** out) {
+  if (!ctx) return G16_EINVAL;
+  if (!out || (n && !points) || n >= (size_t(1) << 26)) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  g16_points* h = new (std::nothrow) g16_points();
+  if (!h) return G16_ENOMEM;
+  h->ctx = ctx;
+  h->group = group;
+  h->n = n;
+  h->c = g16_pick_window_g1(n);
+  h->nwin = 254 / h->c + 1;
+  const size_t psz = group == 1 ? 64 : 128;
+  if ((size_t)h->nwin * n >= (size_t(1) << 31)) {
+    delete h;
+    ctx->err = "point set too large for 31-bit table indices";
+    return G16_EINVAL;
+  }
+  if (n) {
+    hipError_t e = hipMalloc(&h->d_tables, (size_t)h->nwin * n * psz);
+    if (e != hipSuccess) {
+      delete h;
+      ctx->err = "hipMalloc(tables) failed";
+      return G16_ENOMEM;
+    }
+    const void* d_src = points;
+    int32_t rc = G16_OK;
+    if (!on_device) {
+      rc = ensure(ctx, ctx->stage_p, n * psz);
+      if (!rc && hipMemcpyAsync(ctx->stage_p.p, points, n * psz, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = G16_EHIP;
+      d_src = ctx->stage_p.p;
+    }
+    if (!rc)
+      rc = group == 1 ? g16_precompute_device_g1(ctx, d_src, n, h->c, h->d_tables)
+                      : g16_precompute_device_g2(ctx, d_src, n, h->c, h->d_tables);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = G16_EHIP;
+    if (rc) {
+      (void)hipFree(h->d_tables);
+      delete h;
+      if (ctx->err.empty()) ctx->err = "point registration failed";
+      return rc;
+    }
+  }
+  *out = h;
+  return G16_OK;
+}
+extern "C" int32_t g16_points_register_g1(g16_ctx* ctx, const void* points, size_t n, g16_points** out) {
+  return points_register(ctx, 1, points, n, false, out);
+}
+extern "C" int32_t g16_points_register_g2(g16_ctx* ctx, const void* points, size_t n, g16_points** out) {
+  return points_register(ctx, 2, points, n, false, out);
+}
+extern "C" int32_t g16_points_register_g1_dev(g16_ctx* ctx, const void* d_points, size_t n, g16_points** out) {
+  return points_register(ctx, 1, d_points, n, true, out);
+}
+extern "C" int32_t g16_points_register_g2_dev(g16_ctx* ctx, const void* d_points, size_t n, g16_points** out) {
+  return points_register(ctx, 2, d_points, n, true, out);
+}
+extern "C" void g16_points_release(g16_points* h) {
+  if (!h) return;
+  if (h->d_tables) {
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    (void)hipFree(h->d_tables);
+  }
+  delete h;
+}
+extern "C" size_t g16_points_count(const g16_points* h) { return h ? h->n : 0; }
+
+// MSM against a registered set; flags: G16_SCALARS_MONT | G16_SCALARS_DEVICE | G16_OUT_PARTIAL
+extern "C" int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const void* scalars, uint32_t flags,
+                                  void* out) {
+  if (!ctx) return G16_EINVAL;
+  if (!pts || !out || pts->ctx != ctx || (pts->n && !scalars)) {
+    ctx->err = "bad argument (null pointer or point set of another context)";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const bool partial = (flags & G16_OUT_PARTIAL) != 0;
+  const size_t psz = pts->group == 1 ? 64 : 128;
+  const size_t out_bytes = partial ? 2 * psz : psz;
+  const size_t n = pts->n;
+  if (n == 0) {
+    memset(out, 0, out_bytes);
+    return G16_OK;
+  }
+  int32_t rc;
+  const void* d_s = scalars;
+  if (!(flags & G16_SCALARS_DEVICE)) {
+    if ((rc = ensure(ctx, ctx->stage_s, n * 32))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_s.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    d_s = ctx->stage_s.p;
+  }
+  if ((rc = ensure(ctx, ctx->stage_o, 512))) return rc;
+  void* d_aff = partial ? nullptr : ctx->stage_o.p;
+  void* d_acc = partial ? ctx->stage_o.p : nullptr;
+  rc = pts->group == 1 ? g16_msm_device_g1(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c)
+                       : g16_msm_device_g2(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_o.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -26,10 +26,10 @@ struct MsmParams {
   uint32_t n;            // number of (scalar, point) pairs
   uint32_t c;            // window bits
   uint32_t nwin;         // number of windows  = FR_BITS / c + 1
-  uint32_t nbuckets;     // nwin << (c-1)  (or 1 << (c-1) when tables fold all windows into one set)
+  uint32_t nbuckets;     // nwin << (c-1)
   uint32_t seg;          // L: max entries per accumulate task
   uint32_t scalars_mont; // 1: scalars are Montgomery Fr limbs (Nim seq[Fr]); 0: canonical LE (.wtns)
-  uint32_t tables;       // 1: points array holds nwin tables [w][i] = 2^(c w) P_i ; single bucket set
+  uint32_t tables;       // 1: points array holds nwin tables [w][i] = 2^(c w) P_i (registered point set)
   uint32_t max_extra;    // capacity of the extra-segment list
 };
 
@@ -63,10 +63,8 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_count(const u256* __rest
   __shared__ uint32_t limbs[9 * MSM_BLOCK];
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= P.n) return;
-  const uint32_t bshift = P.tables ? 0 : (P.c - 1);
-  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t) {
-    atomicAdd(&count[(P.tables ? 0u : (w << bshift)) + k], 1u);
-  });
+  const uint32_t bshift = P.c - 1;
+  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t) { atomicAdd(&count[(w << bshift) + k], 1u); });
 }
 
 static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __restrict__ scalars, MsmParams P,
@@ -76,9 +74,9 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __re
   __shared__ uint32_t limbs[9 * MSM_BLOCK];
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= P.n) return;
-  const uint32_t bshift = P.tables ? 0 : (P.c - 1);
+  const uint32_t bshift = P.c - 1;
   msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t neg) {
-    uint32_t b = (P.tables ? 0u : (w << bshift)) + k;
+    uint32_t b = (w << bshift) + k;
     uint32_t pos = offset[b] + atomicAdd(&cursor[b], 1u);
     // entry = point index (table-major when tables are used) | sign in bit 31
     uint32_t pidx = P.tables ? (w * P.n + i) : i;
@@ -358,7 +356,9 @@ __global__ void __launch_bounds__(RED2_BLOCK) msm_reduce2(const typename C::Acc*
   }
 }
 
-// ---- K7: fold windows (Horner) + canonical affine ----------------------------------------------------
+// ---- K7: fold windows + canonical affine ------------------------------------------------------------
+// c > 0: Horner  sum_w 2^(c w) S_w  (c doublings per window: a serial chain of ~254 doublings);
+// c == 0: the window sums already carry their 2^(c w) factor (precomputed tables) -> plain sum.
 template <class C>
 __global__ void msm_fold(const typename C::Acc* __restrict__ window_sum, uint32_t nwin, uint32_t c,
                          typename C::Aff* __restrict__ out_aff, typename C::Acc* __restrict__ out_acc) {
@@ -371,6 +371,25 @@ __global__ void msm_fold(const typename C::Acc* __restrict__ window_sum, uint32_
   }
   if (out_acc) *out_acc = r;
   if (out_aff) *out_aff = C::to_affine(r);
+}
+
+// ---- registration-time precomputation:  table[w][i] = 2^(c w) * P_i  (affine), w = 0..nwin-1 ---------
+// One thread per point: c doublings per window, one inversion per stored point.  Runs once per circuit
+// (the reference loads ProverPoints once per zkey, zkey_types.nim:36-41); trades HBM capacity
+// (nwin x the point set) for the removal of the serial doubling chain from every MSM.
+template <class C>
+__global__ void __launch_bounds__(MSM_BLOCK) msm_precompute(const typename C::Aff* __restrict__ points, uint32_t n,
+                                                            uint32_t c, uint32_t nwin,
+                                                            typename C::Aff* __restrict__ tables) {
+  uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  typename C::Aff p = points[i];
+  tables[i] = p;
+  typename C::Acc acc = C::from_affine(p);
+  for (uint32_t w = 1; w < nwin; ++w) {
+    for (uint32_t k = 0; k < c; ++k) acc = C::dbl(acc);
+    tables[(size_t)w * n + i] = C::to_affine(acc);
+  }
 }
 
 }  // namespace g16

@@ -55,15 +55,16 @@ struct MsmLayout {
   }
 };
 
-// d_out_aff / d_out_acc: device pointers (either may be null)
+// d_out_aff / d_out_acc: device pointers (either may be null).  table_c != 0: d_points holds the
+// precomputed tables of a registered point set built with window size table_c.
 template <class C>
 static int32_t msm_device(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
-                          typename C::Aff* d_out_aff, typename C::Acc* d_out_acc, const char* tag) {
+                          typename C::Aff* d_out_aff, typename C::Acc* d_out_acc, uint32_t table_c) {
   MsmParams P;
   P.n = (uint32_t)n;
-  P.c = pick_window(n);
+  P.c = table_c ? table_c : pick_window(n);
   P.nwin = FR_BITS / P.c + 1;
-  P.tables = 0;
+  P.tables = table_c ? 1u : 0u;
   P.nbuckets = P.nwin << (P.c - 1);
   size_t avg = (n >> (P.c - 1)) + 1;
   P.seg = (uint32_t)(((2 * avg + 31) / 32) * 32);
@@ -89,7 +90,6 @@ static int32_t msm_device(g16_ctx* ctx, const void* d_scalars, uint32_t flags, c
   auto* wsum = (typename C::Acc*)(ws + L.wsum);
   const auto* scalars = (const u256*)d_scalars;
   const auto* points = (const typename C::Aff*)d_points;
-  (void)tag;
 
   // count + cursor are adjacent: one memset
   HIPCHK(ctx, hipMemsetAsync(ws + L.count, 0, L.offset - L.count, ctx->stream));
@@ -114,10 +114,10 @@ static int32_t msm_device(g16_ctx* ctx, const void* d_scalars, uint32_t flags, c
   const uint32_t nchunks = P.nbuckets / RED_CHUNK;
   KLAUNCH(ctx, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>, (nchunks + MSM_BLOCK - 1) / MSM_BLOCK,
           MSM_BLOCK, 0, partial, offset, P.nbuckets, chunkR, chunkA);
-  const uint32_t nsets = P.tables ? 1u : P.nwin;
+  const uint32_t nsets = P.nwin;
   KLAUNCH(ctx, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", msm_reduce2<C>, nsets, RED2_BLOCK,
           RED2_BLOCK * sizeof(typename C::Acc), chunkR, chunkA, nchunks / nsets, wsum);
-  KLAUNCH(ctx, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets, P.c, d_out_aff, d_out_acc);
+  KLAUNCH(ctx, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets, P.tables ? 0u : P.c, d_out_aff, d_out_acc);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
@@ -136,6 +136,15 @@ template <class C>
 static int32_t sum_partials_device(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff) {
   KLAUNCH(ctx, "sum_partials", sum_partials_kernel<C>, 1, 64, 0, (const typename C::Acc*)d_parts, count,
           (typename C::Aff*)d_out_aff);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+template <class C>
+static int32_t precompute_device(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
+  const uint32_t nwin = FR_BITS / c + 1;
+  KLAUNCH(ctx, "msm_precompute", msm_precompute<C>, (uint32_t)((n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0,
+          (const typename C::Aff*)d_points, (uint32_t)n, c, nwin, (typename C::Aff*)d_tables);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }

@@ -94,3 +94,36 @@ def test_msm_partials_sum(ctx, orc):
         dp = torch.frombuffer(bytearray(pts[64 * a:64 * b]), dtype=torch.uint8).cuda()
         parts += ctx.msm(1, ds.data_ptr(), dp.data_ptr(), b - a, partial=True)
     assert ctx.sum_partials(1, parts, 3) == full
+
+
+@pytest.mark.parametrize("group,n", [(1, 1), (1, 700), (1, 1 << 13), (2, 700), (2, 1 << 12)])
+def test_msm_registered_points_tables(ctx, orc, group, n):
+    """registered point set (precomputed 2^(cw) P_i tables) == plain MSM == oracle; also std scalars,
+    infinity points inside the set, and reuse of one registration across several scalar vectors."""
+    psz = PSZ[group]
+    ks, pts = I.points_with_logs(orc, group, n, seed=71)
+    if n >= 700:   # plant infinities (snarkjs keys contain (0,0) for unused wires, curves.nim:95-98)
+        pts = bytearray(pts)
+        for i in (3, 77, n - 1):
+            pts[psz * i:psz * (i + 1)] = bytes(psz)
+            ks[i] = 0
+        pts = bytes(pts)
+    h = ctx.register_points(group, pts, n)
+    try:
+        for seed, dist in ((72, "uniform"), (73, "circom"), (74, "uniform")):
+            sc = I.uniform_scalars(n, seed) if dist == "uniform" else I.circom_like_scalars(n, seed)
+            got = ctx.msm_points(h, I.fr_mont_bytes(sc))
+            assert got == I.expected_from_logs(group, sc, ks), (dist, seed)
+            assert got == ctx.msm(group, I.fr_mont_bytes(sc), pts, n)
+        sc = I.uniform_scalars(n, 75)
+        assert ctx.msm_points(h, I.fr_std_bytes(sc), mont=False) == I.expected_from_logs(group, sc, ks)
+        part = ctx.msm_points(h, I.fr_mont_bytes(sc), partial=True)
+        assert ctx.sum_partials(group, part, 1) == I.expected_from_logs(group, sc, ks)
+    finally:
+        h.release()
+
+
+def test_msm_registered_empty(ctx):
+    h = ctx.register_points(1, b"", 0)
+    assert ctx.msm_points(h, b"") == INF[1]
+    h.release()
