@@ -97,11 +97,68 @@ size_t g16_points_count(const g16_points* pts);
  * per proof for msmMultiThreadedG1/G2 (groth16/prover.nim:282,288,294,301,302). */
 int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const void* scalars, uint32_t flags, void* out);
 
+/* ---- fixed-base multiples of the generators: out[i] = scalars[i] * gen1 (resp. gen2) --------------------
+ * replaces the `y ** gen1` / `y ** gen2` comprehensions of the fake trusted setup
+ * (groth16/fake_setup.nim:258-261, 273-277, 290-302; generators: curves.nim:112-124).  Used to build
+ * proving keys for the synthetic benchmark circuits on the GPU box.  Host pointers. */
+int32_t g16_fixed_base_g1(g16_ctx* ctx, const void* scalars, uint32_t scalar_flags, size_t n, void* out_points);
+int32_t g16_fixed_base_g2(g16_ctx* ctx, const void* scalars, uint32_t scalar_flags, size_t n, void* out_points);
+
 /* ---- NTT: replaces forwardNTT / inverseNTT (groth16/math/ntt.nim:55-77, 139-161) ------------------- */
 /* natural order in and out; forward unscaled, inverse includes 1/n; omega = gen28^(2^(28-log2n))
  * (math/domain.nim:26-33).  src/dst: n = 2^log2n Fr elements (Montgomery), host memory. 0 <= log2n <= 28 */
 int32_t g16_ntt_fr(g16_ctx* ctx, const void* src, void* dst, uint32_t log2n, int32_t inverse);
 int32_t g16_ntt_fr_dev(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int32_t inverse);
+
+/* ---- quotient: replaces computeSnarkjsScalarCoeffs (flavour 1, groth16/prover.nim:158-181) and
+ *      computeQuotientPointwise (flavour 0, prover.nim:118-148) -------------------------------------------
+ * Az, Bz, Cz, out: n = 2^log2n Fr elements (Montgomery).  Snarkjs: out[j] = A1[j]*B1[j] - C1[j] on the coset
+ * eta*H, eta = w_(2n); JensGroth: the n coefficients of (A*B - C)/Z.  log2n <= 27. */
+#define G16_FLAVOUR_JENSGROTH 0u /* zkey_types.nim:11 */
+#define G16_FLAVOUR_SNARKJS 1u   /* zkey_types.nim:12 */
+int32_t g16_quotient(g16_ctx* ctx, const void* Az, const void* Bz, const void* Cz, uint32_t log2n, uint32_t flavour,
+                     void* out);
+int32_t g16_quotient_dev(g16_ctx* ctx, const void* d_Az, const void* d_Bz, const void* d_Cz, uint32_t log2n,
+                         uint32_t flavour, void* d_out);
+
+/* ---- proving key + proof: replaces generateProofWithMask (groth16/prover.nim:215-304) -----------------
+ * g16_pkey_create uploads a ZKey (zkey_types.nim:54-59) once: the five ProverPoints arrays become
+ * registered point sets, ZKey.coeffs becomes a device CSR for buildABC (prover.nim:56-73). */
+typedef struct g16_pkey g16_pkey;
+typedef struct {          /* one Coeff (zkey_types.nim:48-52) */
+  uint32_t matrix;        /* 0 = MatrixA, 1 = MatrixB (MatrixC is rejected, as prover.nim:67 raises) */
+  uint32_t row;           /* 0 .. domainSize-1 */
+  uint32_t col;           /* 0 .. nvars-1 */
+  uint32_t reserved;
+  uint8_t value[32];      /* Fr, Montgomery */
+} g16_coeff;
+typedef struct {
+  uint32_t nvars, npubs;  /* GrothHeader (zkey_types.nim:14-22) */
+  uint32_t log2_domain;   /* logDomainSize */
+  uint32_t flavour;       /* G16_FLAVOUR_* */
+  const void *pointsA1, *pointsB1; /* nvars G1 points each          (zkey_types.nim:37-38) */
+  const void* pointsB2;            /* nvars G2 points               (:39) */
+  const void* pointsC1;            /* nvars - npubs - 1 G1 points   (:40) */
+  const void* pointsH1;            /* domainSize G1 points          (:41) */
+  const g16_coeff* coeffs;
+  size_t ncoeffs;
+  const void *alpha1, *beta1, *delta1; /* SpecPoints G1 (zkey_types.nim:24-31) */
+  const void *beta2, *delta2;          /* SpecPoints G2 */
+} g16_pkey_desc;
+typedef struct { /* Proof (prover.nim:37-43) minus publicIO (= witness[0..npubs], which the caller already has) */
+  uint8_t pi_a[64];
+  uint8_t pi_b[128];
+  uint8_t pi_c[64];
+} g16_proof;
+int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* desc, g16_pkey** out);
+void g16_pkey_destroy(g16_pkey* key);
+/* witness: nvars Fr values (flags: G16_SCALARS_MONT for Nim seq[Fr], G16_SCALARS_STD for raw .wtns,
+ * | G16_SCALARS_DEVICE); mask_r / mask_s: Fr Montgomery (Mask, prover.nim:210-213), NULL = zero
+ * (generateProofWithTrivialMask, prover.nim:308-310). */
+int32_t g16_prove(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, const void* mask_r,
+                  const void* mask_s, g16_proof* out);
+/* buildABC alone (prover.nim:56-73): out_abc = Az | Bz | Cz, 3 * domainSize Fr (Montgomery), host memory */
+int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, void* out_abc);
 
 /* ---- profiling ---------------------------------------------------------------------------------- */
 /* when enabled, every kernel launch is bracketed by HIP events on the context's stream */

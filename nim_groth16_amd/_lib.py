@@ -4,6 +4,7 @@ from __future__ import annotations
 import ctypes
 import json
 import os
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -17,8 +18,21 @@ SYMBOLS = [
     "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_msm_points",
+    "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
+    "g16_pkey_destroy", "g16_prove", "g16_build_abc",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
 ]
+
+
+class PkeyDesc(ctypes.Structure):
+    """g16_pkey_desc (include/g16hip.h)"""
+    _fields_ = [("nvars", ctypes.c_uint32), ("npubs", ctypes.c_uint32), ("log2_domain", ctypes.c_uint32),
+                ("flavour", ctypes.c_uint32),
+                ("pointsA1", ctypes.c_void_p), ("pointsB1", ctypes.c_void_p), ("pointsB2", ctypes.c_void_p),
+                ("pointsC1", ctypes.c_void_p), ("pointsH1", ctypes.c_void_p),
+                ("coeffs", ctypes.c_void_p), ("ncoeffs", ctypes.c_size_t),
+                ("alpha1", ctypes.c_void_p), ("beta1", ctypes.c_void_p), ("delta1", ctypes.c_void_p),
+                ("beta2", ctypes.c_void_p), ("delta2", ctypes.c_void_p)]
 
 
 class G16Error(RuntimeError):
@@ -72,13 +86,23 @@ def load_library():
     lib.g16_points_count.argtypes = [vp]
     lib.g16_points_count.restype = sz
     lib.g16_msm_points.argtypes = [vp, vp, vp, u32, vp]
+    lib.g16_fixed_base_g1.argtypes = [vp, vp, u32, sz, vp]
+    lib.g16_fixed_base_g2.argtypes = [vp, vp, u32, sz, vp]
+    lib.g16_quotient.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    lib.g16_quotient_dev.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    lib.g16_pkey_create.argtypes = [vp, ctypes.POINTER(PkeyDesc), ctypes.POINTER(vp)]
+    lib.g16_pkey_destroy.argtypes = [vp]
+    lib.g16_pkey_destroy.restype = None
+    lib.g16_prove.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+    lib.g16_build_abc.argtypes = [vp, vp, vp, u32, vp]
     lib.g16_ntt_fr.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_ntt_fr_dev.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_profile_enable.argtypes = [vp, i32]
     lib.g16_profile_reset.argtypes = [vp]
     lib.g16_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
     for name in SYMBOLS:
-        if name not in ("g16_ctx_destroy", "g16_last_error", "g16_points_release", "g16_points_count"):
+        if name not in ("g16_ctx_destroy", "g16_last_error", "g16_points_release", "g16_points_count",
+                        "g16_pkey_destroy"):
             getattr(lib, name).restype = i32
     _lib = lib
     return lib
@@ -107,9 +131,12 @@ class Context:
             raise G16Error(rc, "g16_ctx_create failed (no usable HIP device?)")
         self._h = h
         self.device = device
+        self._children = weakref.WeakSet()   # point sets / proving keys that must die before the context
 
     def close(self):
         if getattr(self, "_h", None):
+            for child in list(self._children):
+                child._free()
             self._lib.g16_ctx_destroy(self._h)
             self._h = None
 
@@ -164,6 +191,23 @@ class Context:
         self._check(self._lib.g16_msm_points(self._h, pts._h, _buf(scalars) if pts.n else None, flags, out))
         return out.raw
 
+    def fixed_base(self, group: int, scalars: bytes, mont: bool = True) -> bytes:
+        """scalars[i] * generator -> affine points (fake_setup.nim:258-261 `y ** gen1/gen2`)."""
+        n = len(scalars) // 32
+        psz = 64 if group == 1 else 128
+        out = ctypes.create_string_buffer(max(n, 1) * psz)
+        fn = self._lib.g16_fixed_base_g1 if group == 1 else self._lib.g16_fixed_base_g2
+        self._check(fn(self._h, _buf(scalars) if n else None, SCALARS_MONT if mont else 0, n, out))
+        return out.raw[: n * psz]
+
+    def quotient(self, Az, Bz, Cz, log2n: int, flavour: int, out=None, device: bool = False):
+        if device:
+            self._check(self._lib.g16_quotient_dev(self._h, _buf(Az), _buf(Bz), _buf(Cz), log2n, flavour, _buf(out)))
+            return None
+        res = ctypes.create_string_buffer(32 << log2n)
+        self._check(self._lib.g16_quotient(self._h, _buf(Az), _buf(Bz), _buf(Cz), log2n, flavour, res))
+        return res.raw
+
     def sum_partials(self, group: int, xyzz: bytes, count: int) -> bytes:
         psz = 64 if group == 1 else 128
         out = ctypes.create_string_buffer(psz)
@@ -194,20 +238,66 @@ class Context:
         return json.loads(buf.value.decode())
 
 
+class ProvingKey:
+    """Device-resident proving key (g16_pkey): registered ProverPoints + CSR of the A/B matrices."""
+
+    def __init__(self, ctx: Context, desc: PkeyDesc, keepalive):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx._check(ctx._lib.g16_pkey_create(ctx._h, ctypes.byref(desc), ctypes.byref(h)))
+        self._h = h
+        self.nvars, self.npubs, self.log2n = desc.nvars, desc.npubs, desc.log2_domain
+        ctx._children.add(self)
+        del keepalive
+
+    def prove(self, witness, mont: bool = True, r: bytes = None, s: bytes = None, device: bool = False):
+        """-> (pi_a 64 B, pi_b 128 B, pi_c 64 B); r, s: Fr Montgomery bytes or None (trivial mask)."""
+        out = ctypes.create_string_buffer(256)
+        flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
+        self.ctx._check(self.ctx._lib.g16_prove(self.ctx._h, self._h, _buf(witness), flags,
+                                                _buf(r) if r else None, _buf(s) if s else None, out))
+        raw = out.raw
+        return raw[0:64], raw[64:192], raw[192:256]
+
+    def build_abc(self, witness: bytes, mont: bool = True):
+        n = 1 << self.log2n
+        out = ctypes.create_string_buffer(3 * n * 32)
+        self.ctx._check(self.ctx._lib.g16_build_abc(self.ctx._h, self._h, _buf(witness),
+                                                    SCALARS_MONT if mont else 0, out))
+        raw = out.raw
+        return raw[: 32 * n], raw[32 * n: 64 * n], raw[64 * n:]
+
+    def _free(self):
+        if self._h and self.ctx._h:
+            self.ctx._lib.g16_pkey_destroy(self._h)
+        self._h = None
+
+    destroy = _free
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
 class PointSet:
     """Device-resident point set with precomputed window tables (g16_points)."""
 
     def __init__(self, ctx: Context, handle, group: int, n: int):
         self.ctx, self._h, self.group, self.n = ctx, handle, group, n
+        ctx._children.add(self)
 
-    def release(self):
-        if self._h:
+    def _free(self):
+        if self._h and self.ctx._h:
             self.ctx._lib.g16_points_release(self._h)
-            self._h = None
+        self._h = None
+
+    release = _free
 
     def __del__(self):
         try:
-            self.release()
+            self._free()
         except Exception:
             pass
 

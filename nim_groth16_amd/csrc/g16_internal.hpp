@@ -31,8 +31,14 @@ struct g16_ctx {
   Buf stage_p;   // staged points
   Buf stage_o;   // result slot
   Buf ntt_tw;    // twiddle table
-  Buf ntt_tmp;   // ping-pong buffer
+  Buf ntt_tmp;   // ping-pong buffers
+  Buf coset[2];  // eta^(+-i)/n tables (ntt_make_coset_table)
+  Buf quot;      // 6n work area of the quotient pipeline
+  Buf prove;     // per-proof scalars: witness, Az|Bz|Cz, qs
+  Buf fb_table[2];  // fixed-base tables of gen1 / gen2
+  bool fb_ready[2] = {false, false};
   uint32_t tw_log2n = 0xffffffffu;
+  uint32_t coset_log2n[2] = {0xffffffffu, 0xffffffffu};
   // profiling
   bool profiling = false;
   std::vector<ProfEntry> prof;
@@ -104,6 +110,10 @@ int32_t g16_msm_device_g2(g16_ctx* ctx, const void* d_scalars, uint32_t flags, c
 int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 uint32_t g16_pick_window_g1(size_t n);
+int32_t g16_fixed_base_device_g1(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
+                                 void* d_out);
+int32_t g16_fixed_base_device_g2(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
+                                 void* d_out);
 
 // device-resident point set with precomputed window tables
 struct g16_points {
@@ -116,3 +126,7 @@ struct g16_points {
 int32_t g16_sum_partials_device_g1(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
 int32_t g16_sum_partials_device_g2(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse);
+// computeSnarkjsScalarCoeffs (flavour 1, prover.nim:158-181) / computeQuotientPointwise (flavour 0, :118-148)
+// d_a, d_b, d_c, d_out: n elements each (device); inputs are not modified
+int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, uint32_t log2n,
+                            int flavour, void* d_out);

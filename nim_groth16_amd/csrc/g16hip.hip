@@ -29,7 +29,9 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (g16_ctx::Buf* b : {&ctx->ws, &ctx->stage_s, &ctx->stage_p, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp})
+  for (g16_ctx::Buf* b : {&ctx->ws, &ctx->stage_s, &ctx->stage_p, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
+                          &ctx->coset[0], &ctx->coset[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
+                          &ctx->fb_table[1]})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->prof) {
     (void)hipEventDestroy(e.e0);
@@ -221,6 +223,37 @@ extern "C" void g16_points_release(g16_points* h) {
   delete h;
 }
 extern "C" size_t g16_points_count(const g16_points* h) { return h ? h->n : 0; }
+
+// out[i] = scalars[i] * generator  (`y ** gen1` / `y ** gen2`, fake_setup.nim:258-261); host pointers
+static int32_t fixed_base(g16_ctx* ctx, int group, const void* scalars, uint32_t flags, size_t n, void* out) {
+  if (!ctx) return G16_EINVAL;
+  if (n && (!scalars || !out)) {
+    ctx->err = "null pointer argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t psz = group == 1 ? 64 : 128;
+  int32_t rc;
+  g16_ctx::Buf& tb = ctx->fb_table[group - 1];
+  if ((rc = ensure(ctx, tb, 32 * 255 * psz))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_s, n * 32 + 32))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_p, n * psz + psz))) return rc;
+  if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->stage_s.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
+  rc = group == 1 ? g16_fixed_base_device_g1(ctx, tb.p, ctx->fb_ready[0], ctx->stage_s.p, mont, n, ctx->stage_p.p)
+                  : g16_fixed_base_device_g2(ctx, tb.p, ctx->fb_ready[1], ctx->stage_s.p, mont, n, ctx->stage_p.p);
+  if (rc) return rc;
+  ctx->fb_ready[group - 1] = true;
+  if (n) HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_p.p, n * psz, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+extern "C" int32_t g16_fixed_base_g1(g16_ctx* ctx, const void* scalars, uint32_t flags, size_t n, void* out) {
+  return fixed_base(ctx, 1, scalars, flags, n, out);
+}
+extern "C" int32_t g16_fixed_base_g2(g16_ctx* ctx, const void* scalars, uint32_t flags, size_t n, void* out) {
+  return fixed_base(ctx, 2, scalars, flags, n, out);
+}
 
 // MSM against a registered set; flags: G16_SCALARS_MONT | G16_SCALARS_DEVICE | G16_OUT_PARTIAL
 extern "C" int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const void* scalars, uint32_t flags,

@@ -392,4 +392,40 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_precompute(const typename C::Af
   }
 }
 
+// ---- fixed-base multiples of the group generator: out[i] = k_i * G  (fake_setup.nim:258-261 `y ** gen`) ----
+// table[w*255 + d-1] = d * 2^(8w) * G, w < 32, d = 1..255 (built once per context)
+template <class C>
+__global__ void __launch_bounds__(256) fixed_base_table(typename C::Aff gen, typename C::Aff* __restrict__ table) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 32 * 255) return;
+  uint32_t w = t / 255, d = t % 255 + 1;
+  typename C::Acc acc = C::mul_small(C::from_affine(gen), d);
+  for (uint32_t i = 0; i < 8 * w; ++i) acc = C::dbl(acc);
+  table[t] = C::to_affine(acc);
+}
+template <class C>
+__global__ void __launch_bounds__(256) fixed_base_mul(const u256* __restrict__ scalars, uint32_t mont, uint32_t n,
+                                                      const typename C::Aff* __restrict__ table,
+                                                      typename C::Aff* __restrict__ out) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u256 s = scalars[i];
+  if (mont) s = Fr::from_mont(s);
+  typename C::Acc acc = C::acc_inf();
+#pragma unroll 1
+  for (uint32_t j = 0; j < 8; ++j) {
+    uint32_t limb = s.v[0];
+    // rotate limbs so that the index stays static (a runtime-indexed register array would go to scratch)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) s.v[q] = s.v[q + 1];
+    s.v[7] = limb;
+#pragma unroll 1
+    for (uint32_t b = 0; b < 4; ++b) {
+      uint32_t d = (limb >> (8 * b)) & 0xff;
+      if (d) C::madd(acc, table[(4 * j + b) * 255 + d - 1]);
+    }
+  }
+  out[i] = C::to_affine(acc);
+}
+
 }  // namespace g16

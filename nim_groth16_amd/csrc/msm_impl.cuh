@@ -148,3 +148,17 @@ static int32_t precompute_device(g16_ctx* ctx, const void* d_points, size_t n, u
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
+
+// gen: group generator in Montgomery affine form; d_table: 32*255 points (built here when !table_ready)
+template <class C>
+static int32_t fixed_base_device(g16_ctx* ctx, const typename C::Aff& gen, void* d_table, bool table_ready,
+                                 const void* d_scalars, uint32_t mont, size_t n, void* d_out) {
+  if (!table_ready)
+    KLAUNCH(ctx, "fixed_base_table", fixed_base_table<C>, (32 * 255 + 255) / 256, 256, 0, gen,
+            (typename C::Aff*)d_table);
+  if (n)
+    KLAUNCH(ctx, "fixed_base_mul", fixed_base_mul<C>, (uint32_t)((n + 255) / 256), 256, 0, (const u256*)d_scalars,
+            mont, (uint32_t)n, (const typename C::Aff*)d_table, (typename C::Aff*)d_out);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}

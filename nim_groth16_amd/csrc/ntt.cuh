@@ -64,12 +64,20 @@ constexpr int NTT_TILE = 2048;  // elements per workgroup tile (64 KB of LDS)
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return __brev(x) >> (32 - bits); }
 
-// one pass: rho radix-2 stages of B sub-transforms of size R = 2^rho per workgroup
+// one pass: rho radix-2 stages of B sub-transforms of size R = 2^rho per workgroup.
+// blockIdx.y selects one of several independent vectors (x + y*xstride -> y + y*ystride): the prover
+// transforms Az, Bz, Cz together (prover.nim:167-169 runs them as three tasks).
+// `scale` (last pass only): out[i] *= scale[i] instead of the plain 1/n of the inverse transform -- used
+// to fuse multiplyByPowers (prover.nim:96-106) into the inverse NTT of shiftEvalDomain (prover.nim:109-113).
 static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restrict__ x, u256* __restrict__ y,
                                                       const u256* __restrict__ tw, uint32_t log2n, uint32_t log2s,
-                                                      uint32_t rho, uint32_t log2b, int inverse, int last) {
+                                                      uint32_t rho, uint32_t log2b, int inverse, int last,
+                                                      size_t xstride, size_t ystride,
+                                                      const u256* __restrict__ scale) {
   extern __shared__ __align__(16) unsigned char smem[];
   u256* lds = reinterpret_cast<u256*>(smem);
+  x += xstride * blockIdx.y;
+  y += ystride * blockIdx.y;
   const uint32_t R = 1u << rho, B = 1u << log2b;
   const uint32_t nR = 1u << (log2n - rho);  // n / R = number of bases = input stride between r's
   const uint32_t base0 = blockIdx.x << log2b;
@@ -112,11 +120,42 @@ static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restr
       uint64_t ex = ((uint64_t)j * q) << log2s;
       uint32_t em = (uint32_t)(ex & ((1ull << log2n) - 1));
       if (em) v = Fr::mul(v, ntt_tw(tw, em, log2n, inverse));
-    } else if (inverse) {
-      v = Fr::mul(v, tw[(1u << log2n) >> 1]);  // * 1/n
     }
-    y[(size_t)k + ((size_t)(((size_t)j << rho) + q) << log2s)] = v;
+    const size_t oi = (size_t)k + ((size_t)(((size_t)j << rho) + q) << log2s);
+    if (last) {
+      if (scale) v = Fr::mul(v, scale[oi]);
+      else if (inverse) v = Fr::mul(v, tw[(1u << log2n) >> 1]);  // * 1/n
+    }
+    y[oi] = v;
   }
+}
+
+// scale tables for the coset shift, eta = w_(2n) (prover.nim:163):
+//   mode 0: tab[i] = eta^i / n      (inverse NTT + multiplyByPowers(eta),    prover.nim:110-112)
+//   mode 1: tab[i] = eta^(-i) / n   (inverse NTT + multiplyByPowers(1/eta),  prover.nim:142-143)
+static __global__ void __launch_bounds__(256) ntt_make_coset_table(u256* __restrict__ tab, uint32_t log2n, int mode) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t n = 1u << log2n;
+  if (i >= n) return;
+  u256 ninv = Fr::one();
+  for (uint32_t k = 0; k < log2n; ++k) ninv = Fr::div2(ninv);
+  u256 eta = ntt_omega(log2n + 1);
+  uint32_t e = mode ? (2 * n - i) % (2 * n) : i;   // eta^(2n) = 1
+  tab[i] = Fr::mul(fr_pow_u32(eta, e), ninv);
+}
+
+// ys[j] = (A1[j]*B1[j] - C1[j]) [* invZ]   (prover.nim:175-176 and :141)
+static __global__ void __launch_bounds__(256) fr_abc_pointwise(const u256* __restrict__ a, const u256* __restrict__ b,
+                                                        const u256* __restrict__ c, u256* __restrict__ out,
+                                                        uint32_t n, int mul_invz, uint32_t log2n) {
+  uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  u256 v = Fr::sub(Fr::mul(a[j], b[j]), c[j]);
+  if (mul_invz) {
+    // invZ1 = 1 / (eta^n - 1), eta = w_(2n)  =>  eta^n = -1  =>  invZ1 = -1/2   (prover.nim:127-128)
+    v = Fr::neg(Fr::div2(v));
+  }
+  out[j] = v;
 }
 
 }  // namespace g16

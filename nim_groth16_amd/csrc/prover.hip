@@ -1,0 +1,307 @@
+// Proving-key residency and the per-proof launch sequence: the GPU counterpart of
+// generateProofWithMask (reference groth16/prover.nim:215-304).
+//   buildABC                      prover.nim:56-73     -> abc_spmv kernel (CSR built once per key)
+//   computeSnarkjsScalarCoeffs /  prover.nim:158-181   -> g16_quotient_device (ntt.hip)
+//   computeQuotientPointwise      prover.nim:118-148
+//   5 x msmMultiThreaded          prover.nim:282-302   -> msm_device on the registered point tables
+//   mask algebra (`**`, `+=`)     prover.nim:279-302   -> O(1) curve operations on the host, as in the
+//                                                         reference (curves.nim:136-214); not a hot loop
+#include <algorithm>
+#include <new>
+
+#include "g16_internal.hpp"
+#include "ec.cuh"
+
+using namespace g16;
+
+struct g16_pkey {
+  g16_ctx* ctx = nullptr;
+  uint32_t nvars = 0, npubs = 0, log2n = 0, flavour = 1;
+  g16_points *A1 = nullptr, *B1 = nullptr, *B2 = nullptr, *C1 = nullptr, *H1 = nullptr;
+  // CSR of the A and B matrices (zkey section 4 / ZKey.coeffs, zkey_types.nim:48-59)
+  uint32_t* d_rowptr = nullptr;  // [2][n+1]
+  uint32_t* d_col = nullptr;
+  u256* d_val = nullptr;
+  size_t ncoeffs = 0;
+  g1_aff alpha1, beta1, delta1;
+  g2_aff beta2, delta2;
+};
+
+// ---- buildABC ---------------------------------------------------------------------------------------
+// one thread per row: Az[r] = sum A[r][c] z[c], Bz likewise, Cz = Az * Bz   (prover.nim:56-73)
+static __global__ void __launch_bounds__(256) abc_spmv(const uint32_t* __restrict__ rowptr,
+                                                       const uint32_t* __restrict__ col,
+                                                       const u256* __restrict__ val, const u256* __restrict__ wit,
+                                                       uint32_t wit_mont, uint32_t n, u256* __restrict__ abc) {
+  uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  u256 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    u256 a = Fr::zero();
+    const uint32_t* rp = rowptr + (size_t)m * (n + 1);
+    for (uint32_t e = rp[r]; e < rp[r + 1]; ++e) {
+      u256 w = wit[col[e]];
+      if (!wit_mont) w = Fr::to_mont(w);
+      a = Fr::add(a, Fr::mul(val[e], w));
+    }
+    acc[m] = a;
+  }
+  abc[r] = acc[0];
+  abc[(size_t)n + r] = acc[1];
+  abc[2 * (size_t)n + r] = Fr::mul(acc[0], acc[1]);
+}
+
+// ---- host-side O(1) curve helpers (the reference does these on the host too: curves.nim:136-214) ------
+template <class C>
+static typename C::Aff host_mul(const u256& k_std, const typename C::Aff& p) {
+  typename C::Acc acc = C::acc_inf();
+  const typename C::Acc base = C::from_affine(p);
+  bool started = false;
+  for (int i = 7; i >= 0; --i)
+    for (int b = 31; b >= 0; --b) {
+      if (started) acc = C::dbl(acc);
+      if ((k_std.v[i] >> b) & 1) {
+        C::add(acc, base);
+        started = true;
+      }
+    }
+  return C::to_affine(acc);
+}
+template <class C>
+static typename C::Aff host_add(const typename C::Aff& a, const typename C::Aff& b) {
+  typename C::Acc acc = C::from_affine(a);
+  C::madd(acc, b);
+  return C::to_affine(acc);
+}
+
+extern "C" void g16_pkey_destroy(g16_pkey* k) {
+  if (!k) return;
+  for (g16_points* p : {k->A1, k->B1, k->B2, k->C1, k->H1}) g16_points_release(p);
+  if (k->ctx) {
+    (void)hipSetDevice(k->ctx->device);
+    (void)hipStreamSynchronize(k->ctx->stream);
+  }
+  if (k->d_rowptr) (void)hipFree(k->d_rowptr);
+  if (k->d_col) (void)hipFree(k->d_col);
+  if (k->d_val) (void)hipFree(k->d_val);
+  delete k;
+}
+
+extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pkey** out) {
+  if (!ctx) return G16_EINVAL;
+  if (!d || !out) {
+    ctx->err = "null argument";
+    return G16_EINVAL;
+  }
+  *out = nullptr;
+  const size_t n = size_t(1) << d->log2_domain;
+  // shape rules of generateProofWithMask (prover.nim:236, 270-276)
+  if (d->log2_domain > 27 || d->nvars == 0 || d->npubs + 1 > d->nvars || d->flavour > 1 || !d->pointsA1 ||
+      !d->pointsB1 || !d->pointsB2 || !d->pointsH1 || (d->nvars - d->npubs - 1 > 0 && !d->pointsC1) ||
+      (d->ncoeffs && !d->coeffs) || !d->alpha1 || !d->beta1 || !d->delta1 || !d->beta2 || !d->delta2) {
+    ctx->err = "bad proving-key description";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  g16_pkey* k = new (std::nothrow) g16_pkey();
+  if (!k) return G16_ENOMEM;
+  k->ctx = ctx;
+  k->nvars = d->nvars;
+  k->npubs = d->npubs;
+  k->log2n = d->log2_domain;
+  k->flavour = d->flavour;
+  memcpy(&k->alpha1, d->alpha1, 64);
+  memcpy(&k->beta1, d->beta1, 64);
+  memcpy(&k->delta1, d->delta1, 64);
+  memcpy(&k->beta2, d->beta2, 128);
+  memcpy(&k->delta2, d->delta2, 128);
+  int32_t rc;
+#define TRY(x)               \
+  if ((rc = (x)) != G16_OK) { \
+    g16_pkey_destroy(k);     \
+    return rc;               \
+  }
+  TRY(g16_points_register_g1(ctx, d->pointsA1, d->nvars, &k->A1));
+  TRY(g16_points_register_g1(ctx, d->pointsB1, d->nvars, &k->B1));
+  TRY(g16_points_register_g2(ctx, d->pointsB2, d->nvars, &k->B2));
+  TRY(g16_points_register_g1(ctx, d->pointsC1, d->nvars - d->npubs - 1, &k->C1));
+  TRY(g16_points_register_g1(ctx, d->pointsH1, n, &k->H1));
+  // CSR by counting sort on (matrix, row): A entries first, then B (sum order is irrelevant mod r)
+  const g16_coeff* cf = (const g16_coeff*)d->coeffs;
+  std::vector<uint32_t> rowptr(2 * (n + 1), 0);
+  {
+    std::vector<uint32_t> cnt(2 * (n + 1), 0);
+    for (size_t e = 0; e < d->ncoeffs; ++e) {
+      if (cf[e].matrix > 1 || cf[e].row >= n || cf[e].col >= d->nvars) {
+        // MatrixC entries make the reference's buildABC raise (prover.nim:67)
+        ctx->err = "coefficient entry out of range (matrix must be 0=A or 1=B)";
+        g16_pkey_destroy(k);
+        return G16_EINVAL;
+      }
+      cnt[cf[e].matrix * (n + 1) + cf[e].row]++;
+    }
+    uint32_t pos = 0;
+    for (int m = 0; m < 2; ++m)
+      for (size_t r = 0; r <= n; ++r) {
+        rowptr[m * (n + 1) + r] = pos;
+        if (r < n) pos += cnt[m * (n + 1) + r];
+      }
+  }
+  std::vector<uint32_t> cols(d->ncoeffs ? d->ncoeffs : 1);
+  std::vector<u256> vals(d->ncoeffs ? d->ncoeffs : 1);
+  {
+    std::vector<uint32_t> cur(rowptr);
+    for (size_t e = 0; e < d->ncoeffs; ++e) {
+      uint32_t& p = cur[cf[e].matrix * (n + 1) + cf[e].row];
+      cols[p] = cf[e].col;
+      memcpy(&vals[p], cf[e].value, 32);
+      ++p;
+    }
+  }
+  k->ncoeffs = d->ncoeffs;
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t {
+    if (hipMalloc(dst, bytes ? bytes : 4) != hipSuccess) return G16_ENOMEM;
+    if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return G16_EHIP;
+    return G16_OK;
+  };
+  TRY(up((void**)&k->d_rowptr, rowptr.data(), rowptr.size() * 4));
+  TRY(up((void**)&k->d_col, cols.data(), d->ncoeffs * 4));
+  TRY(up((void**)&k->d_val, vals.data(), d->ncoeffs * 32));
+#undef TRY
+  *out = k;
+  return G16_OK;
+}
+
+// Az | Bz | Cz for a witness (device buffers); exposed for tests of the buildABC kernel
+static int32_t build_abc_device(g16_ctx* ctx, const g16_pkey* k, const u256* d_wit, uint32_t wit_mont, u256* d_abc) {
+  const uint32_t n = 1u << k->log2n;
+  KLAUNCH(ctx, "abc_spmv", abc_spmv, (n + 255) / 256, 256, 0, k->d_rowptr, k->d_col, k->d_val, d_wit, wit_mont, n,
+          d_abc);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+extern "C" int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, void* out_abc) {
+  if (!ctx) return G16_EINVAL;
+  if (!k || !witness || !out_abc || k->ctx != ctx) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = size_t(1) << k->log2n;
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->prove, ((size_t)k->nvars + 4 * n) * 32))) return rc;
+  u256* d_w = (u256*)ctx->prove.p;
+  u256* d_abc = d_w + k->nvars;
+  HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = build_abc_device(ctx, k, d_w, (flags & G16_SCALARS_MONT) ? 1u : 0u, d_abc))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out_abc, d_abc, 3 * n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+
+extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, const void* mask_r,
+                             const void* mask_s, g16_proof* out) {
+  if (!ctx) return G16_EINVAL;
+  if (!k || !witness || !out || k->ctx != ctx) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = size_t(1) << k->log2n;
+  const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->prove, ((size_t)k->nvars + 4 * n) * 32))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_o, 1024))) return rc;
+  u256* d_w = (u256*)ctx->prove.p;
+  u256* d_abc = d_w + k->nvars;
+  u256* d_qs = d_abc + 3 * n;
+  if (flags & G16_SCALARS_DEVICE)
+    HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  else
+    HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32, hipMemcpyHostToDevice, ctx->stream));
+  // buildABC + quotient  (prover.nim:244-260)
+  if ((rc = build_abc_device(ctx, k, d_w, wit_mont, d_abc))) return rc;
+  if ((rc = g16_quotient_device(ctx, d_abc, d_abc + n, d_abc + 2 * n, k->log2n, (int)k->flavour, d_qs))) return rc;
+  // the five MSMs (prover.nim:282, 288, 294, 301, 302); results land in five device slots
+  char* slots = (char*)ctx->stage_o.p;
+  const uint32_t wflags = wit_mont ? G16_SCALARS_MONT : 0u;
+  if ((rc = g16_msm_device_g1(ctx, d_w, wflags, k->A1->d_tables, k->A1->n, slots + 0, nullptr, k->A1->c))) return rc;
+  if ((rc = g16_msm_device_g1(ctx, d_w, wflags, k->B1->d_tables, k->B1->n, slots + 64, nullptr, k->B1->c))) return rc;
+  if ((rc = g16_msm_device_g2(ctx, d_w, wflags, k->B2->d_tables, k->B2->n, slots + 128, nullptr, k->B2->c))) return rc;
+  if ((rc = g16_msm_device_g1(ctx, d_qs, G16_SCALARS_MONT, k->H1->d_tables, k->H1->n, slots + 256, nullptr, k->H1->c)))
+    return rc;
+  if (k->C1->n) {
+    if ((rc = g16_msm_device_g1(ctx, d_w + k->npubs + 1, wflags, k->C1->d_tables, k->C1->n, slots + 320, nullptr,
+                                k->C1->c)))
+      return rc;
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(slots + 320, 0, 64, ctx->stream));
+  }
+  struct {
+    g1_aff a, b1;
+    g2_aff b2;
+    g1_aff h, c;
+  } res;
+  static_assert(sizeof(res) == 384, "slot layout");
+  HIPCHK(ctx, hipMemcpyAsync(&res, slots, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+
+  // mask scalars -> standard form while the GPU works (prover.nim:267-268)
+  u256 r = Fr::zero(), s = Fr::zero();
+  if (mask_r) memcpy(&r, mask_r, 32);
+  if (mask_s) memcpy(&s, mask_s, 32);
+  const u256 r_std = Fr::from_mont(r), s_std = Fr::from_mont(s);
+  const u256 mrs_std = Fr::from_mont(Fr::neg(Fr::mul(r, s)));
+  const g1_aff r_delta1 = host_mul<G1>(r_std, k->delta1);
+  const g1_aff s_delta1 = host_mul<G1>(s_std, k->delta1);
+  const g2_aff s_delta2 = host_mul<G2>(s_std, k->delta2);
+  const g1_aff mrs_delta1 = host_mul<G1>(mrs_std, k->delta1);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+
+  // prover.nim:279-302
+  g1_aff pi_a = host_add<G1>(host_add<G1>(k->alpha1, r_delta1), res.a);
+  g1_aff rho = host_add<G1>(host_add<G1>(k->beta1, s_delta1), res.b1);
+  g2_aff pi_b = host_add<G2>(host_add<G2>(k->beta2, s_delta2), res.b2);
+  g1_aff pi_c = host_mul<G1>(s_std, pi_a);
+  pi_c = host_add<G1>(pi_c, host_mul<G1>(r_std, rho));
+  pi_c = host_add<G1>(pi_c, mrs_delta1);
+  pi_c = host_add<G1>(pi_c, res.h);
+  pi_c = host_add<G1>(pi_c, res.c);
+  memcpy(out->pi_a, &pi_a, 64);
+  memcpy(out->pi_b, &pi_b, 128);
+  memcpy(out->pi_c, &pi_c, 64);
+  return G16_OK;
+}
+
+// quotient alone, host pointers (replaces computeSnarkjsScalarCoeffs / computeQuotientPointwise)
+extern "C" int32_t g16_quotient(g16_ctx* ctx, const void* Az, const void* Bz, const void* Cz, uint32_t log2n,
+                                uint32_t flavour, void* out) {
+  if (!ctx) return G16_EINVAL;
+  if (!Az || !Bz || !Cz || !out || log2n > 27 || flavour > 1) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = size_t(1) << log2n;
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->prove, 4 * n * 32))) return rc;
+  u256* d = (u256*)ctx->prove.p;
+  HIPCHK(ctx, hipMemcpyAsync(d, Az, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d + n, Bz, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d + 2 * n, Cz, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = g16_quotient_device(ctx, d, d + n, d + 2 * n, log2n, (int)flavour, d + 3 * n))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, d + 3 * n, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+extern "C" int32_t g16_quotient_dev(g16_ctx* ctx, const void* d_Az, const void* d_Bz, const void* d_Cz, uint32_t log2n,
+                                    uint32_t flavour, void* d_out) {
+  if (!ctx) return G16_EINVAL;
+  if (!d_Az || !d_Bz || !d_Cz || !d_out || log2n > 27 || flavour > 1) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return g16_quotient_device(ctx, d_Az, d_Bz, d_Cz, log2n, (int)flavour, d_out);
+}

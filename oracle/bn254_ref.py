@@ -555,11 +555,13 @@ class ToxicWaste:
         self.alpha, self.beta, self.gamma, self.delta, self.tau = alpha, beta, gamma, delta, tau
 
 
-def fake_circuit_setup(r1cs: R1CS, toxic: ToxicWaste, flavour=SNARKJS, mul_g1=None, mul_g2=None) -> ZKey:
-    """fake_setup.nim:201-326.  mul_g1/mul_g2 let a faster fixed-base multiplier be plugged in
-    (same result: canonical affine points)."""
-    mul_g1 = mul_g1 or (lambda k: G1.mul(k % R, GEN1))
-    mul_g2 = mul_g2 or (lambda k: G2.mul(k % R, GEN2))
+def fake_circuit_setup(r1cs: R1CS, toxic: ToxicWaste, flavour=SNARKJS, batch_g1=None, batch_g2=None) -> ZKey:
+    """fake_setup.nim:201-326.  batch_g1/batch_g2(list of scalars) -> list of affine points let the C
+    oracle's fixed-base multiplier be plugged in for mid-size circuits (same canonical points)."""
+    batch_g1 = batch_g1 or (lambda ks: [G1.mul(k % R, GEN1) for k in ks])
+    batch_g2 = batch_g2 or (lambda ks: [G2.mul(k % R, GEN2) for k in ks])
+    mul_g1 = lambda k: batch_g1([k])[0]     # noqa: E731
+    mul_g2 = lambda k: batch_g2([k])[0]     # noqa: E731
     neqs = len(r1cs.constraints)
     npub = r1cs.nPubIn + r1cs.nPubOut
     logDom = ceiling_log2(neqs + npub + 1)
@@ -600,21 +602,21 @@ def fake_circuit_setup(r1cs: R1CS, toxic: ToxicWaste, flavour=SNARKJS, mul_g1=No
     tausA = [dot(c) for c in colA]
     tausB = [dot(c) for c in colB]
     tausC = [dot(c) for c in colC]
-    zk.pointsA1 = [mul_g1(y) for y in tausA]
-    zk.pointsB1 = [mul_g1(y) for y in tausB]
-    zk.pointsB2 = [mul_g2(y) for y in tausB]
+    zk.pointsA1 = batch_g1(tausA)
+    zk.pointsB1 = batch_g1(tausB)
+    zk.pointsB2 = batch_g2(tausB)
     gamma_inv, delta_inv = inv_fr(toxic.gamma), inv_fr(toxic.delta)
     # fake_setup.nim:273-277: inv * (beta*A_j + alpha*B1_j + C_j)  == ((beta*a + alpha*b + c) * inv) * G
     comb = [(toxic.beta * tausA[j] + toxic.alpha * tausB[j] + tausC[j]) % R for j in range(nvars)]
-    zk.pointsIC = [mul_g1(gamma_inv * comb[j] % R) for j in range(npub + 1)]
-    zk.pointsC1 = [mul_g1(delta_inv * comb[j] % R) for j in range(npub + 1, nvars)]
+    zk.pointsIC = batch_g1([gamma_inv * comb[j] % R for j in range(npub + 1)])
+    zk.pointsC1 = batch_g1([delta_inv * comb[j] % R for j in range(npub + 1, nvars)])
     if flavour == JENS_GROTH:
         # fake_setup.nim:290-292  [delta^-1 tau^i Z(tau)]
-        zk.pointsH1 = [mul_g1(delta_inv * pow(tau, i, R) % R * ztau % R) for i in range(dom)]
+        zk.pointsH1 = batch_g1([delta_inv * pow(tau, i, R) % R * ztau % R for i in range(dom)])
     else:
         # fake_setup.nim:299-302  [delta^-1 L_{2i+1}(tau)] on the doubled domain
         D2 = Domain(2 * dom)
-        zk.pointsH1 = [mul_g1(delta_inv * eval_lagrange_poly_at(D2, 2 * i + 1, tau) % R) for i in range(dom)]
+        zk.pointsH1 = batch_g1([delta_inv * eval_lagrange_poly_at(D2, 2 * i + 1, tau) % R for i in range(dom)])
     zk.coeffs = r1cs_to_coeffs(r1cs)
     return zk
 

@@ -1,0 +1,123 @@
+"""GPU parity for the prover-level path (through the C ABI): fixed-base setup, buildABC, quotient (both
+flavours) and the full proof, bit-exact against the oracle; plus the reference's own check -- the proof
+verifies (tests/groth16/testProver.nim:59-73) -- on the reference's toy circuit and on a synthetic chain."""
+import pytest
+
+from oracle import bn254_ref as o
+from tests import inputs as I
+
+pytestmark = pytest.mark.gpu
+
+
+def _zkey_to_oracle(zk):
+    """product ZKey (bytes) -> oracle ZKey (ints), so the oracle can verify / re-prove it."""
+    z = o.ZKey()
+    h = zk.header
+    z.flavour = o.SNARKJS if h.flavour == 1 else o.JENS_GROTH
+    z.nvars, z.npubs, z.domainSize, z.logDomainSize = h.nvars, h.npubs, h.domainSize, h.logDomainSize
+    g1s = lambda b: [o.g1_from_bytes(b[i:i + 64]) for i in range(0, len(b), 64)]      # noqa: E731
+    g2s = lambda b: [o.g2_from_bytes(b[i:i + 128]) for i in range(0, len(b), 128)]    # noqa: E731
+    sp = zk.specPoints
+    z.alpha1, z.beta1, z.delta1 = g1s(sp.alpha1)[0], g1s(sp.beta1)[0], g1s(sp.delta1)[0]
+    z.beta2, z.gamma2, z.delta2 = g2s(sp.beta2)[0], g2s(sp.gamma2)[0], g2s(sp.delta2)[0]
+    z.pointsIC = g1s(zk.pointsIC)
+    p = zk.pPoints
+    z.pointsA1, z.pointsB1, z.pointsB2 = g1s(p.pointsA1), g1s(p.pointsB1), g2s(p.pointsB2)
+    z.pointsC1, z.pointsH1 = g1s(p.pointsC1), g1s(p.pointsH1)
+    z.coeffs = [(m, r, c, o.fr_from_mont_bytes(v)) for (m, r, c, v) in zk.coeffs]
+    return z
+
+
+def _toxic(seed):
+    rng = o.SplitMix64(seed)
+    return [rng.fr() for _ in range(5)]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_fixed_base_vs_oracle(ctx, orc, group):
+    ks = I.uniform_scalars(300, 11) + [0, 1, o.R - 1, 255, 256, 1 << 248]
+    sb = I.fr_mont_bytes(ks)
+    assert ctx.fixed_base(group, sb) == orc.fixed_base(group, sb)
+    assert ctx.fixed_base(group, I.fr_std_bytes(ks), mont=False) == orc.fixed_base(group, sb)
+    assert ctx.fixed_base(group, b"") == b""
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_toy_circuit_setup_prove_verify_bit_exact(ctx, flavour):
+    """the reference's fixture (tests/groth16/testProver.nim:17-73), both flavours, masks (0,0) and random"""
+    from nim_groth16_amd import Mask, Witness, generateProofWithMask, generateProofWithTrivialMask
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    a, b, g, d, t = _toxic(5)
+    toy = o.toy_r1cs()
+    zk = fakeCircuitSetup(R1CS(8, 1, 1, 3, toy.constraints), ToxicWaste(a, b, g, d, t), flavour, ctx)
+    oz = o.fake_circuit_setup(toy, o.ToxicWaste(a, b, g, d, t), o.SNARKJS if flavour else o.JENS_GROTH)
+    z2 = _zkey_to_oracle(zk)
+    for f in ("alpha1", "beta1", "delta1", "beta2", "gamma2", "delta2", "pointsIC", "pointsA1", "pointsB1",
+              "pointsB2", "pointsC1", "pointsH1", "coeffs"):
+        assert getattr(z2, f) == getattr(oz, f), f
+    wt = Witness("bn128", 8, I.fr_mont_bytes(o.TOY_WITNESS))
+    rng = o.SplitMix64(6)
+    for (r, s) in ((0, 0), (rng.fr(), rng.fr()), (1, o.R - 1)):
+        pr = generateProofWithMask(0, False, zk, wt, Mask(r, s), ctx) if (r or s) else \
+            generateProofWithTrivialMask(0, False, zk, wt, ctx)
+        ref = o.generate_proof_with_mask(oz, o.TOY_WITNESS, r, s)
+        assert o.g1_from_bytes(pr.pi_a) == ref.pi_a
+        assert o.g2_from_bytes(pr.pi_b) == ref.pi_b
+        assert o.g1_from_bytes(pr.pi_c) == ref.pi_c
+        assert I.fr_from_mont(pr.publicIO) == ref.publicIO == [1, 2023, 1022]   # prover.nim:238-240
+        assert o.verify_proof(oz, ref)                      # verifier.nim:31-52
+
+
+@pytest.mark.parametrize("log2n", [1, 3, 8, 11, 14])
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_quotient_vs_oracle(ctx, orc, log2n, flavour):
+    n = 1 << log2n
+    A, B, C = (I.uniform_scalars(n, s) for s in (21, 22, 23))
+    got = ctx.quotient(I.fr_mont_bytes(A), I.fr_mont_bytes(B), I.fr_mont_bytes(C), log2n, flavour)
+    if flavour == 1:
+        assert got == orc.quotient_snarkjs(I.fr_mont_bytes(A), I.fr_mont_bytes(B), I.fr_mont_bytes(C), log2n)
+    if log2n <= 8:
+        exp = o.compute_snarkjs_scalar_coeffs(A, B, C) if flavour else o.compute_quotient_pointwise(A, B, C)
+        assert I.fr_from_mont(got) == exp
+
+
+def test_synthetic_chain_prove_matches_oracle_and_verifies(ctx, orc):
+    """squaring chain, m = 2^9 - 2 constraints (domain 2^9): buildABC, proof bytes and verification"""
+    from nim_groth16_amd import Mask, Witness, generateProofWithMask, loadProvingKey
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import squaringChain
+    m = (1 << 9) - 2
+    r1cs, wit = squaringChain(m, seed=4)
+    a, b, g, d, t = _toxic(5)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(a, b, g, d, t), 1, ctx)
+    assert zk.header.domainSize == 1 << 9 and zk.header.nvars == m + 2
+    # oracle setup with the C oracle's fixed-base multiplier
+    bg1 = lambda ks: [o.g1_from_bytes(x) for x in _chunks(orc.fixed_base(1, I.fr_mont_bytes(ks)), 64)]    # noqa: E731
+    bg2 = lambda ks: [o.g2_from_bytes(x) for x in _chunks(orc.fixed_base(2, I.fr_mont_bytes(ks)), 128)]   # noqa: E731
+    oz = o.fake_circuit_setup(o.R1CS(r1cs.nWires, 1, 0, 1, r1cs.constraints), o.ToxicWaste(a, b, g, d, t),
+                              o.SNARKJS, bg1, bg2)
+    z2 = _zkey_to_oracle(zk)
+    assert z2.pointsA1 == oz.pointsA1 and z2.pointsB2 == oz.pointsB2 and z2.pointsC1 == oz.pointsC1
+    assert z2.pointsH1 == oz.pointsH1 and z2.coeffs == oz.coeffs
+    pk = loadProvingKey(zk, ctx)
+    wb = I.fr_mont_bytes(wit)
+    Az, Bz, Cz = pk.build_abc(wb)
+    eA, eB, eC = o.build_abc(oz.coeffs, oz.domainSize, wit)
+    assert I.fr_from_mont(Az) == eA and I.fr_from_mont(Bz) == eB and I.fr_from_mont(Cz) == eC
+    rng = o.SplitMix64(6)
+    r, s = rng.fr(), rng.fr()
+    pr = generateProofWithMask(0, False, zk, Witness("bn128", m + 2, wb), Mask(r, s), ctx, pkey=pk)
+    msm1 = lambda cs, ps: o.g1_from_bytes(orc.msm(1, I.fr_mont_bytes(cs), b"".join(o.g1_to_bytes(p) for p in ps)))   # noqa: E731
+    msm2 = lambda cs, ps: o.g2_from_bytes(orc.msm(2, I.fr_mont_bytes(cs), b"".join(o.g2_to_bytes(p) for p in ps)))   # noqa: E731
+    ref = o.generate_proof_with_mask(oz, wit, r, s, msm_g1=msm1, msm_g2=msm2)
+    assert (o.g1_from_bytes(pr.pi_a), o.g2_from_bytes(pr.pi_b), o.g1_from_bytes(pr.pi_c)) == \
+        (ref.pi_a, ref.pi_b, ref.pi_c)
+    assert o.verify_proof(oz, ref)
+    # std-form witness (raw .wtns layout) gives the same proof
+    pa, pb, pc = pk.prove(I.fr_std_bytes(wit), mont=False, r=o.fr_to_mont_bytes(r), s=o.fr_to_mont_bytes(s))
+    assert (pa, pb, pc) == (pr.pi_a, pr.pi_b, pr.pi_c)
+    pk.destroy()
+
+
+def _chunks(b, k):
+    return [b[i:i + k] for i in range(0, len(b), k)]
