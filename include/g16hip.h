@@ -46,6 +46,7 @@ typedef struct g16_points g16_points; /* device-resident point set (ProverPoints
 #define G16_SCALARS_STD 0u  /* canonical little-endian (raw .wtns values)                              */
 #define G16_SCALARS_DEVICE 2u /* g16_msm_points only: the scalar pointer is a device (HBM) pointer       */
 #define G16_OUT_PARTIAL 4u    /* g16_msm_points only: write the 128/256-byte XYZZ partial, not the affine */
+#define G16_OUT_DEVICE 8u     /* g16_prove_partials only: the output pointer is a device pointer           */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int32_t g16_ctx_create(int32_t device, g16_ctx** out);
@@ -144,6 +145,9 @@ typedef struct {
   size_t ncoeffs;
   const void *alpha1, *beta1, *delta1; /* SpecPoints G1 (zkey_types.nim:24-31) */
   const void *beta2, *delta2;          /* SpecPoints G2 */
+  /* multi-GPU: this key keeps only index range [N*i/count, N*(i+1)/count) of each point set -- the contiguous
+   * chunks of msmMultiThreadedG1/G2 (msm.nim:105-115) with one chunk per GPU.  0/0 or 0/1 = whole key. */
+  uint32_t shard_index, shard_count;
 } g16_pkey_desc;
 typedef struct { /* Proof (prover.nim:37-43) minus publicIO (= witness[0..npubs], which the caller already has) */
   uint8_t pi_a[64];
@@ -157,6 +161,17 @@ void g16_pkey_destroy(g16_pkey* key);
  * (generateProofWithTrivialMask, prover.nim:308-310). */
 int32_t g16_prove(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, const void* mask_r,
                   const void* mask_s, g16_proof* out);
+/* The two halves of g16_prove, for a proof sharded over several GPUs (one g16_ctx + one sharded key per GPU):
+ *  g16_prove_partials: buildABC + quotient (replicated) and the five MSMs over this key's index ranges;
+ *      writes G16_PARTIALS_BYTES = 768 bytes: XYZZ accumulators A1 | B1 | B2 (256 B) | H1 | C1.
+ *      flags: G16_SCALARS_MONT/STD | G16_SCALARS_DEVICE (witness in HBM) | G16_OUT_DEVICE (output in HBM).
+ *  g16_prove_combine: `count` gathered records (rank order; e.g. from an RCCL all-gather) are summed per MSM
+ *      -- the `res += sync pending[k]` of msm.nim:117-119 across GPUs -- and the mask algebra of
+ *      prover.nim:279-302 yields the proof.  flags: G16_SCALARS_DEVICE if `partials` is a device pointer. */
+#define G16_PARTIALS_BYTES 768
+int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, void* out_partials);
+int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* key, const void* partials, size_t count, uint32_t flags,
+                          const void* mask_r, const void* mask_s, g16_proof* out);
 /* buildABC alone (prover.nim:56-73): out_abc = Az | Bz | Cz, 3 * domainSize Fr (Montgomery), host memory */
 int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, void* out_abc);
 

@@ -9,7 +9,8 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 G16_OK, G16_EINVAL, G16_ENODEV, G16_EHIP, G16_ENOMEM, G16_ESELFTEST = 0, -1, -2, -3, -4, -5
-SCALARS_MONT, SCALARS_STD, SCALARS_DEVICE, OUT_PARTIAL = 1, 0, 2, 4
+SCALARS_MONT, SCALARS_STD, SCALARS_DEVICE, OUT_PARTIAL, OUT_DEVICE = 1, 0, 2, 4, 8
+PARTIALS_BYTES = 768
 
 # every symbol include/g16hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -19,7 +20,7 @@ SYMBOLS = [
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_msm_points",
     "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
-    "g16_pkey_destroy", "g16_prove", "g16_build_abc",
+    "g16_pkey_destroy", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
 ]
 
@@ -32,7 +33,8 @@ class PkeyDesc(ctypes.Structure):
                 ("pointsC1", ctypes.c_void_p), ("pointsH1", ctypes.c_void_p),
                 ("coeffs", ctypes.c_void_p), ("ncoeffs", ctypes.c_size_t),
                 ("alpha1", ctypes.c_void_p), ("beta1", ctypes.c_void_p), ("delta1", ctypes.c_void_p),
-                ("beta2", ctypes.c_void_p), ("delta2", ctypes.c_void_p)]
+                ("beta2", ctypes.c_void_p), ("delta2", ctypes.c_void_p),
+                ("shard_index", ctypes.c_uint32), ("shard_count", ctypes.c_uint32)]
 
 
 class G16Error(RuntimeError):
@@ -95,6 +97,8 @@ def load_library():
     lib.g16_pkey_destroy.restype = None
     lib.g16_prove.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     lib.g16_build_abc.argtypes = [vp, vp, vp, u32, vp]
+    lib.g16_prove_partials.argtypes = [vp, vp, vp, u32, vp]
+    lib.g16_prove_combine.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp]
     lib.g16_ntt_fr.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_ntt_fr_dev.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_profile_enable.argtypes = [vp, i32]
@@ -256,6 +260,25 @@ class ProvingKey:
         flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
         self.ctx._check(self.ctx._lib.g16_prove(self.ctx._h, self._h, _buf(witness), flags,
                                                 _buf(r) if r else None, _buf(s) if s else None, out))
+        raw = out.raw
+        return raw[0:64], raw[64:192], raw[192:256]
+
+    def prove_partials(self, witness, mont: bool = True, device: bool = False, out=None):
+        """this rank's five XYZZ MSM partials (768 bytes); out = device pointer to write them into HBM."""
+        flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
+        if out is not None:
+            self.ctx._check(self.ctx._lib.g16_prove_partials(self.ctx._h, self._h, _buf(witness), flags | OUT_DEVICE,
+                                                             _buf(out)))
+            return None
+        buf = ctypes.create_string_buffer(PARTIALS_BYTES)
+        self.ctx._check(self.ctx._lib.g16_prove_partials(self.ctx._h, self._h, _buf(witness), flags, buf))
+        return buf.raw
+
+    def prove_combine(self, partials, count: int, r: bytes = None, s: bytes = None, device: bool = False):
+        out = ctypes.create_string_buffer(256)
+        self.ctx._check(self.ctx._lib.g16_prove_combine(self.ctx._h, self._h, _buf(partials), count,
+                                                        SCALARS_DEVICE if device else 0,
+                                                        _buf(r) if r else None, _buf(s) if s else None, out))
         raw = out.raw
         return raw[0:64], raw[64:192], raw[192:256]
 

@@ -17,6 +17,11 @@ using namespace g16;
 struct g16_pkey {
   g16_ctx* ctx = nullptr;
   uint32_t nvars = 0, npubs = 0, log2n = 0, flavour = 1;
+  // this key holds the index ranges [lo, hi) of each point set (msm.nim:105-115 chunk rule over shard_count ranks)
+  uint32_t shard_index = 0, shard_count = 1;
+  size_t w_lo = 0, w_hi = 0;   // A1 / B1 / B2 : range of wires
+  size_t c_lo = 0, c_hi = 0;   // C1           : range inside witness[npubs+1 ..]
+  size_t h_lo = 0, h_hi = 0;   // H1           : range of domain indices
   g16_points *A1 = nullptr, *B1 = nullptr, *B2 = nullptr, *C1 = nullptr, *H1 = nullptr;
   // CSR of the A and B matrices (zkey section 4 / ZKey.coeffs, zkey_types.nim:48-59)
   uint32_t* d_rowptr = nullptr;  // [2][n+1]
@@ -122,11 +127,27 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
     g16_pkey_destroy(k);     \
     return rc;               \
   }
-  TRY(g16_points_register_g1(ctx, d->pointsA1, d->nvars, &k->A1));
-  TRY(g16_points_register_g1(ctx, d->pointsB1, d->nvars, &k->B1));
-  TRY(g16_points_register_g2(ctx, d->pointsB2, d->nvars, &k->B2));
-  TRY(g16_points_register_g1(ctx, d->pointsC1, d->nvars - d->npubs - 1, &k->C1));
-  TRY(g16_points_register_g1(ctx, d->pointsH1, n, &k->H1));
+  // contiguous index ranges per rank: b = (N*(k+1)) div ntasks   (msm.nim:107-115)
+  k->shard_count = d->shard_count ? d->shard_count : 1;
+  k->shard_index = d->shard_index;
+  if (k->shard_index >= k->shard_count) {
+    ctx->err = "shard_index >= shard_count";
+    g16_pkey_destroy(k);
+    return G16_EINVAL;
+  }
+  auto range = [&](size_t N, size_t& lo, size_t& hi) {
+    lo = (N * k->shard_index) / k->shard_count;
+    hi = (N * (k->shard_index + 1)) / k->shard_count;
+  };
+  range(d->nvars, k->w_lo, k->w_hi);
+  range(d->nvars - d->npubs - 1, k->c_lo, k->c_hi);
+  range(n, k->h_lo, k->h_hi);
+  TRY(g16_points_register_g1(ctx, (const char*)d->pointsA1 + 64 * k->w_lo, k->w_hi - k->w_lo, &k->A1));
+  TRY(g16_points_register_g1(ctx, (const char*)d->pointsB1 + 64 * k->w_lo, k->w_hi - k->w_lo, &k->B1));
+  TRY(g16_points_register_g2(ctx, (const char*)d->pointsB2 + 128 * k->w_lo, k->w_hi - k->w_lo, &k->B2));
+  TRY(g16_points_register_g1(ctx, d->pointsC1 ? (const char*)d->pointsC1 + 64 * k->c_lo : nullptr,
+                             k->c_hi - k->c_lo, &k->C1));
+  TRY(g16_points_register_g1(ctx, (const char*)d->pointsH1 + 64 * k->h_lo, k->h_hi - k->h_lo, &k->H1));
   // CSR by counting sort on (matrix, row): A entries first, then B (sum order is irrelevant mod r)
   const g16_coeff* cf = (const g16_coeff*)d->coeffs;
   std::vector<uint32_t> rowptr(2 * (n + 1), 0);
@@ -201,10 +222,14 @@ extern "C" int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* k, const void* wi
   return G16_OK;
 }
 
-extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, const void* mask_r,
-                             const void* mask_s, g16_proof* out) {
+// record of the five MSM partials of one rank: XYZZ accumulators (Montgomery), fixed order
+//   [0,128) A1 | [128,256) B1 | [256,512) B2 (G2) | [512,640) H1 | [640,768) C1
+static constexpr size_t PART_A = 0, PART_B1 = 128, PART_B2 = 256, PART_H = 512, PART_C = 640, PART_BYTES = 768;
+
+extern "C" int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
+                                      void* out_partials) {
   if (!ctx) return G16_EINVAL;
-  if (!k || !witness || !out || k->ctx != ctx) {
+  if (!k || !witness || !out_partials || k->ctx != ctx) {
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
@@ -213,41 +238,88 @@ extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witnes
   const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
   int32_t rc;
   if ((rc = ensure(ctx, ctx->prove, ((size_t)k->nvars + 4 * n) * 32))) return rc;
-  if ((rc = ensure(ctx, ctx->stage_o, 1024))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_o, 2048))) return rc;
   u256* d_w = (u256*)ctx->prove.p;
   u256* d_abc = d_w + k->nvars;
   u256* d_qs = d_abc + 3 * n;
-  if (flags & G16_SCALARS_DEVICE)
-    HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32, hipMemcpyDeviceToDevice, ctx->stream));
-  else
-    HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32, hipMemcpyHostToDevice, ctx->stream));
-  // buildABC + quotient  (prover.nim:244-260)
+  HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32,
+                             (flags & G16_SCALARS_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                             ctx->stream));
+  // buildABC + quotient (prover.nim:244-260); replicated on every rank of a sharded proof: ~1 ms, no exchange
   if ((rc = build_abc_device(ctx, k, d_w, wit_mont, d_abc))) return rc;
   if ((rc = g16_quotient_device(ctx, d_abc, d_abc + n, d_abc + 2 * n, k->log2n, (int)k->flavour, d_qs))) return rc;
-  // the five MSMs (prover.nim:282, 288, 294, 301, 302); results land in five device slots
+  // the five MSMs (prover.nim:282, 288, 294, 301, 302) over this key's index ranges
   char* slots = (char*)ctx->stage_o.p;
+  HIPCHK(ctx, hipMemsetAsync(slots, 0, PART_BYTES, ctx->stream));   // empty range -> XYZZ infinity (all zero)
   const uint32_t wflags = wit_mont ? G16_SCALARS_MONT : 0u;
-  if ((rc = g16_msm_device_g1(ctx, d_w, wflags, k->A1->d_tables, k->A1->n, slots + 0, nullptr, k->A1->c))) return rc;
-  if ((rc = g16_msm_device_g1(ctx, d_w, wflags, k->B1->d_tables, k->B1->n, slots + 64, nullptr, k->B1->c))) return rc;
-  if ((rc = g16_msm_device_g2(ctx, d_w, wflags, k->B2->d_tables, k->B2->n, slots + 128, nullptr, k->B2->c))) return rc;
-  if ((rc = g16_msm_device_g1(ctx, d_qs, G16_SCALARS_MONT, k->H1->d_tables, k->H1->n, slots + 256, nullptr, k->H1->c)))
-    return rc;
-  if (k->C1->n) {
-    if ((rc = g16_msm_device_g1(ctx, d_w + k->npubs + 1, wflags, k->C1->d_tables, k->C1->n, slots + 320, nullptr,
-                                k->C1->c)))
-      return rc;
-  } else {
-    HIPCHK(ctx, hipMemsetAsync(slots + 320, 0, 64, ctx->stream));
+  struct Job {
+    const g16_points* pts;
+    const u256* scalars;
+    uint32_t flags;
+    size_t slot;
+  } jobs[5] = {{k->A1, d_w + k->w_lo, wflags, PART_A},
+               {k->B1, d_w + k->w_lo, wflags, PART_B1},
+               {k->B2, d_w + k->w_lo, wflags, PART_B2},
+               {k->H1, d_qs + k->h_lo, G16_SCALARS_MONT, PART_H},
+               {k->C1, d_w + k->npubs + 1 + k->c_lo, wflags, PART_C}};
+  for (const Job& j : jobs) {
+    if (!j.pts->n) continue;
+    rc = j.pts->group == 1
+             ? g16_msm_device_g1(ctx, j.scalars, j.flags, j.pts->d_tables, j.pts->n, nullptr, slots + j.slot, j.pts->c)
+             : g16_msm_device_g2(ctx, j.scalars, j.flags, j.pts->d_tables, j.pts->n, nullptr, slots + j.slot, j.pts->c);
+    if (rc) return rc;
   }
+  HIPCHK(ctx, hipMemcpyAsync(out_partials, slots, PART_BYTES,
+                             (flags & G16_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return G16_OK;
+}
+
+// one workgroup per MSM: res = sum over ranks of that MSM's partial, then canonical affine
+// (`res += sync pending[k]`, msm.nim:117-119, across GPUs instead of threads)
+static __global__ void prove_combine_kernel(const unsigned char* __restrict__ gathered, uint32_t count,
+                                            unsigned char* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const uint32_t b = blockIdx.x;
+  if (b == 2) {
+    g2_acc r = G2::acc_inf();
+    for (uint32_t i = 0; i < count; ++i) G2::add(r, *(const g2_acc*)(gathered + (size_t)i * PART_BYTES + PART_B2));
+    *(g2_aff*)(out + 128) = G2::to_affine(r);
+  } else {
+    const size_t src = b == 0 ? PART_A : b == 1 ? PART_B1 : b == 3 ? PART_H : PART_C;
+    const size_t dst = b == 0 ? 0 : b == 1 ? 64 : b == 3 ? 256 : 320;
+    g1_acc r = G1::acc_inf();
+    for (uint32_t i = 0; i < count; ++i) G1::add(r, *(const g1_acc*)(gathered + (size_t)i * PART_BYTES + src));
+    *(g1_aff*)(out + dst) = G1::to_affine(r);
+  }
+}
+
+extern "C" int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* k, const void* partials, size_t count,
+                                     uint32_t flags, const void* mask_r, const void* mask_s, g16_proof* out) {
+  if (!ctx) return G16_EINVAL;
+  if (!k || !partials || !out || k->ctx != ctx || count == 0 || count > 1024) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->stage_p, count * PART_BYTES))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_o, 2048))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->stage_p.p, partials, count * PART_BYTES,
+                             (flags & G16_SCALARS_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                             ctx->stream));
+  unsigned char* d_res = (unsigned char*)ctx->stage_o.p + 1024;
+  KLAUNCH(ctx, "prove_combine", prove_combine_kernel, 5, 64, 0, (const unsigned char*)ctx->stage_p.p, (uint32_t)count,
+          d_res);
   struct {
     g1_aff a, b1;
     g2_aff b2;
     g1_aff h, c;
   } res;
   static_assert(sizeof(res) == 384, "slot layout");
-  HIPCHK(ctx, hipMemcpyAsync(&res, slots, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
 
-  // mask scalars -> standard form while the GPU works (prover.nim:267-268)
+  // mask scalars -> standard form and the delta multiples while the GPU works (prover.nim:267-268)
   u256 r = Fr::zero(), s = Fr::zero();
   if (mask_r) memcpy(&r, mask_r, 32);
   if (mask_s) memcpy(&s, mask_s, 32);
@@ -272,6 +344,26 @@ extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witnes
   memcpy(out->pi_b, &pi_b, 128);
   memcpy(out->pi_c, &pi_c, 64);
   return G16_OK;
+}
+
+extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, const void* mask_r,
+                             const void* mask_s, g16_proof* out) {
+  if (!ctx) return G16_EINVAL;
+  if (!k || !witness || !out || k->ctx != ctx) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  if (k->shard_count != 1) {
+    ctx->err = "g16_prove needs an unsharded key; use g16_prove_partials + g16_prove_combine";
+    return G16_EINVAL;
+  }
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->stage_o, 2048))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_s, PART_BYTES))) return rc;
+  // partials stay in HBM (stage_s is free again once the witness has been copied into the prove buffer)
+  unsigned char* d_part = (unsigned char*)ctx->stage_s.p;
+  if ((rc = g16_prove_partials(ctx, k, witness, flags | G16_OUT_DEVICE, d_part))) return rc;
+  return g16_prove_combine(ctx, k, d_part, 1, G16_SCALARS_DEVICE, mask_r, mask_s, out);
 }
 
 // quotient alone, host pointers (replaces computeSnarkjsScalarCoeffs / computeQuotientPointwise)

@@ -39,8 +39,9 @@ def _cbuf(b: bytes):
     return ctypes.create_string_buffer(b, len(b)) if b else ctypes.create_string_buffer(1)
 
 
-def loadProvingKey(zkey: ZKey, ctx=None) -> ProvingKey:
-    """Uploads the ZKey once (the reference parses it once per run, files/zkey.nim:241-245)."""
+def loadProvingKey(zkey: ZKey, ctx=None, shard_index: int = 0, shard_count: int = 1) -> ProvingKey:
+    """Uploads the ZKey once (the reference parses it once per run, files/zkey.nim:241-245).  With
+    shard_count > 1 only this rank's contiguous index range of every point set is kept (msm.nim:105-115)."""
     ctx = ctx or default_context()
     hdr, pts, spec = zkey.header, zkey.pPoints, zkey.specPoints
     # shape asserts of generateProofWithMask (prover.nim:270-276)
@@ -53,7 +54,8 @@ def loadProvingKey(zkey: ZKey, ctx=None) -> ProvingKey:
                                spec.delta2)]
     addr = [ctypes.cast(b, ctypes.c_void_p) for b in bufs]
     desc = PkeyDesc(hdr.nvars, hdr.npubs, hdr.logDomainSize, hdr.flavour, addr[0], addr[1], addr[2], addr[3],
-                    addr[4], addr[5], len(zkey.coeffs), addr[6], addr[7], addr[8], addr[9], addr[10])
+                    addr[4], addr[5], len(zkey.coeffs), addr[6], addr[7], addr[8], addr[9], addr[10],
+                    shard_index, shard_count)
     return ProvingKey(ctx, desc, bufs)
 
 

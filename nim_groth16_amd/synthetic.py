@@ -29,10 +29,22 @@ class SplitMix64:
         return v % R
 
 
+def _fr_stream(seed: int, count: int):
+    """== [SplitMix64(seed).fr() for _ in range(count)], vectorised (the state is seed + (i+1)*golden)."""
+    import numpy as np
+    idx = np.arange(1, 4 * count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & _M64) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    raw = z.astype("<u8").tobytes()
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") % R for i in range(count)]
+
+
 def squaringChain(m: int, seed: int = 4, w0: int = 3):
     """-> (R1CS, witness values as ints)."""
-    rng = SplitMix64(seed)
-    ks = [rng.fr() for _ in range(m)]
+    ks = _fr_stream(seed, m)
 
     def wire(i):
         return i + 2 if i < m else 1

@@ -414,3 +414,26 @@ int orc_quotient_snarkjs(const void* Az, const void* Bz, const void* Cz, int log
   for (int k = 0; k < 3; ++k) free(v[k]);
   return t[0].rc | t[1].rc | t[2].rc;
 }
+
+/* buildABC (prover.nim:56-73).  coeffs: packed 48-byte entries {u32 matrix, u32 row, u32 col, u32 pad, Fr value
+ * (Montgomery)} -- the g16_coeff layout of include/g16hip.h; out = Az | Bz | Cz (3n Fr). */
+int orc_build_abc(const void* coeffs, size_t ncoeffs, const void* witness, int log2n, void* out) {
+  size_t n = (size_t)1 << log2n;
+  fe* A = (fe*)out;
+  fe* B = A + n;
+  fe* C = B + n;
+  memset(out, 0, 3 * n * sizeof(fe));
+  const unsigned char* p = (const unsigned char*)coeffs;
+  const fe* w = (const fe*)witness;
+  for (size_t e = 0; e < ncoeffs; ++e, p += 48) {
+    uint32_t m, row, col;
+    fe v, t;
+    memcpy(&m, p, 4); memcpy(&row, p + 4, 4); memcpy(&col, p + 8, 4); memcpy(&v, p + 16, 32);
+    if (m > 1 || row >= n) return -1;   /* MatrixC raises in the reference (prover.nim:67) */
+    fe_mul(&t, &v, &w[col], &MR);
+    fe* dst = m == 0 ? &A[row] : &B[row];
+    fe_add(dst, dst, &t, &MR);
+  }
+  for (size_t i = 0; i < n; ++i) fe_mul(&C[i], &A[i], &B[i], &MR);
+  return 0;
+}

@@ -23,6 +23,7 @@ class Oracle:
         lib.orc_ntt_forward.argtypes = [vp, vp, i32]
         lib.orc_ntt_inverse.argtypes = [vp, vp, i32]
         lib.orc_quotient_snarkjs.argtypes = [vp, vp, vp, i32, vp, i32]
+        lib.orc_build_abc.argtypes = [vp, sz, vp, i32, vp]
 
     @staticmethod
     def _psz(group):
@@ -73,6 +74,14 @@ class Oracle:
         rc = self.lib.orc_quotient_snarkjs(Az, Bz, Cz, log2n, out, 1 if parallel else 0)
         assert rc == 0
         return out.raw
+
+    def build_abc(self, packed_coeffs: bytes, witness: bytes, log2n: int):
+        n = 1 << log2n
+        out = ctypes.create_string_buffer(3 * n * 32)
+        rc = self.lib.orc_build_abc(packed_coeffs, len(packed_coeffs) // 48, witness, log2n, out)
+        assert rc == 0
+        raw = out.raw
+        return raw[:32 * n], raw[32 * n:64 * n], raw[64 * n:]
 
     def field_op(self, field, op, a: bytes, b: bytes = b"\0" * 32) -> bytes:
         out = ctypes.create_string_buffer(32)

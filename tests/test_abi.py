@@ -1,0 +1,82 @@
+"""No-GPU checks of the drop-in boundary: the library loads, exports every symbol include/g16hip.h declares,
+fails loudly (never falls back) without a device, and the host mirrors keep the reference's error behaviour."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "g16hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(g16_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nim_groth16_amd._lib import SYMBOLS, load_library
+    lib = load_library()
+    declared = _header_symbols()
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/g16hip.h but not exported"
+    assert sorted(SYMBOLS) == declared, "ctypes binding list out of sync with the header"
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nim_groth16_amd import Context, G16Error
+    with pytest.raises(G16Error) as e:
+        Context(0)
+    assert e.value.code == -2          # G16_ENODEV
+    from nim_groth16_amd import msmG1
+    with pytest.raises(G16Error):
+        msmG1(bytes(32), bytes(64))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "nim_groth16_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".inc", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"liboracle", r"oracle[/\\]", r"bn254_ref", r"g16_oracle"):
+                    assert not re.search(pat, src, flags=re.M), f"{f} references the oracle ({pat})"
+
+
+def test_host_mirror_asserts_like_the_reference():
+    from nim_groth16_amd.msm import _check_lengths
+    from nim_groth16_amd.ntt import createDomain
+    with pytest.raises(AssertionError):          # msm.nim:97 "incompatible sequence lengths"
+        _check_lengths(bytes(64), bytes(64), 64)
+    with pytest.raises(AssertionError):          # domain.nim:30 "domain must have a power-of-two size"
+        createDomain(12)
+    assert createDomain(1 << 20).logDomainSize == 20
+
+
+def test_synthetic_chain_shapes():
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd.synthetic import squaringChain
+    m = (1 << 6) - 2
+    r1cs, wit = squaringChain(m, seed=4)
+    assert r1cs.nWires == m + 2 and len(wit) == m + 2 and wit[0] == 1
+    npub = r1cs.nPubIn + r1cs.nPubOut
+    assert F.ceilingLog2(m + npub + 1) == 6      # fake_setup.nim:203-206 -> domain 2^6, not 2^7
+    for (A, B, C) in r1cs.constraints:           # every constraint holds on the witness
+        ev = lambda lc: sum(v * wit[w] for w, v in lc) % F.primeR     # noqa: E731
+        assert ev(A) * ev(B) % F.primeR == ev(C)
+
+
+def test_host_scalar_helpers_match_oracle():
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd.fake_setup import lagrangeTaus
+    from oracle import bn254_ref as o
+    assert (F.primeP, F.primeR, F.gen28, F.frMontR, F.frInvMontR) == (o.P, o.R, o.GEN28, o.FR_MONT_R, o.FR_INV_MONT_R)
+    tau = 123456789
+    D = o.Domain(16)
+    assert lagrangeTaus(4, tau) == [o.eval_lagrange_poly_at(D, k, tau) for k in range(16)]
+    xs = [3, 5, 7, 11]
+    assert F.batchInverseFr(xs) == o.batch_inverse_fr(xs)

@@ -1,0 +1,86 @@
+"""The *device* field/curve headers (nim_groth16_amd/csrc/ff.cuh, ec.cuh) compiled with g++ and checked
+against the oracle on the CPU: catches formula errors without a GPU.  (Test build only -- the product never
+runs these on the host for the hot path.)"""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import bn254_ref as o
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_kernels")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(HERE, "libffec_shim.so")
+    src = os.path.join(HERE, "ffec_shim.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
+    return ctypes.CDLL(so)
+
+
+def test_field_formulas(shim):
+    rng = random.Random(1)
+    for field, mod in ((0, o.P), (1, o.R)):
+        Rm = o.MONT % mod
+        Ri = pow(Rm, -1, mod)
+
+        def f(op, a, b=0):
+            r = ctypes.create_string_buffer(32)
+            shim.shim_field_op(field, op, a.to_bytes(32, "little"), b.to_bytes(32, "little"), r)
+            return int.from_bytes(r.raw, "little")
+        special = [0, 1, mod - 1, mod - 2, 2, (mod + 1) // 2, Rm]
+        for t in range(200):
+            a = special[t % 7] if t < 49 else rng.randrange(mod)
+            b = special[(t // 7) % 7] if t < 49 else rng.randrange(mod)
+            assert f(0, a, b) == (a + b) % mod and f(1, a, b) == (a - b) % mod
+            assert f(2, a, b) == a * b * Ri % mod and f(3, a) == a * a * Ri % mod
+            assert f(4, a) == (-a) % mod and f(5, a) == 2 * a % mod
+            assert f(6, a) == a * pow(2, -1, mod) % mod
+            assert f(8, a) == a * Ri % mod and f(9, a) == a * Rm % mod
+        a = rng.randrange(1, mod)
+        assert f(7, a * Rm % mod) == pow(a, -1, mod) * Rm % mod and f(7, 0) == 0
+
+
+def test_fp2_formulas(shim):
+    rng = random.Random(2)
+    enc = lambda x: o.fp_to_mont_bytes(x[0]) + o.fp_to_mont_bytes(x[1])                         # noqa: E731
+    dec = lambda b: (o.fp_from_mont_bytes(b[:32]), o.fp_from_mont_bytes(b[32:64]))              # noqa: E731
+    for _ in range(40):
+        a = (rng.randrange(o.P), rng.randrange(o.P))
+        b = (rng.randrange(o.P), rng.randrange(o.P))
+        for op, fn in ((0, o.fp2_add), (1, o.fp2_sub), (2, o.fp2_mul)):
+            r = ctypes.create_string_buffer(64)
+            shim.shim_fp2_op(op, enc(a), enc(b), r)
+            assert dec(r.raw) == fn(a, b)
+        r = ctypes.create_string_buffer(64)
+        shim.shim_fp2_op(3, enc(a), enc(b), r)
+        assert dec(r.raw) == o.fp2_sqr(a)
+        shim.shim_fp2_op(7, enc(a), enc(b), r)
+        assert dec(r.raw) == o.fp2_inv(a)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_curve_formulas_incl_exceptional_cases(shim, group):
+    rng = random.Random(3)
+    C, gen = (o.G1, o.GEN1) if group == 1 else (o.G2, o.GEN2)
+    enc, dec, psz = (o.g1_to_bytes, o.g1_from_bytes, 64) if group == 1 else (o.g2_to_bytes, o.g2_from_bytes, 128)
+    fn = shim.shim_g1_sum if group == 1 else shim.shim_g2_sum
+
+    def gsum(op, pts, n=None):
+        r = ctypes.create_string_buffer(psz)
+        fn(op, b"".join(enc(p) for p in pts), len(pts) if n is None else n, r)
+        return dec(r.raw)
+    P1, P2, P3 = (C.mul(rng.randrange(o.R), gen) for _ in range(3))
+    cases = [[P1, P2, P3], [P1, P1], [P1, C.neg(P1)], [C.inf, P1, C.inf, P2], [P1, P1, P1, C.neg(P1), P2],
+             [C.inf], [], [P1, P2, C.neg(P2), C.neg(P1)], [P1] * 5]
+    for pts in cases:
+        exp = C.inf
+        for q in pts:
+            exp = C.add(exp, q)
+        assert gsum(0, pts) == exp      # XYZZ += affine (madd), incl. doubling / cancellation / infinity
+        assert gsum(1, pts) == exp      # XYZZ += XYZZ
+    assert gsum(2, [P1], n=12345) == C.mul(12345, P1) and gsum(2, [P1], n=0) == C.inf

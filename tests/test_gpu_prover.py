@@ -121,3 +121,30 @@ def test_synthetic_chain_prove_matches_oracle_and_verifies(ctx, orc):
 
 def _chunks(b, k):
     return [b[i:i + k] for i in range(0, len(b), k)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_proof_single_gpu(ctx, world):
+    """config 4 shape on one device: `world` sharded keys (msm.nim:105-115 ranges), their 768-byte partial
+    records concatenated in rank order, g16_prove_combine -> the same proof as the unsharded key."""
+    from nim_groth16_amd import loadProvingKey
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import squaringChain
+    m = (1 << 7) - 2
+    r1cs, wit = squaringChain(m, seed=9)
+    a, b, g, d, t = _toxic(15)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(a, b, g, d, t), 1, ctx)
+    wb = I.fr_mont_bytes(wit)
+    rng = o.SplitMix64(16)
+    r, s = o.fr_to_mont_bytes(rng.fr()), o.fr_to_mont_bytes(rng.fr())
+    full = loadProvingKey(zk, ctx)
+    want = full.prove(wb, r=r, s=s)
+    keys = [loadProvingKey(zk, ctx, shard_index=k, shard_count=world) for k in range(world)]
+    recs = b"".join(k.prove_partials(wb) for k in keys)
+    assert len(recs) == 768 * world
+    for k in keys:
+        assert k.prove_combine(recs, world, r, s) == want
+    with pytest.raises(Exception):
+        keys[0].prove(wb)                      # a sharded key cannot prove alone
+    for k in keys + [full]:
+        k.destroy()
