@@ -11,6 +11,8 @@
 #include <vector>
 
 
+#include "msm_params.hpp"
+
 struct ProfEntry {
   const char* name;
   hipEvent_t e0, e1;
@@ -26,7 +28,25 @@ struct g16_ctx {
     void* p = nullptr;
     size_t bytes = 0;
   };
-  Buf ws;        // MSM workspace
+  // MSM workspaces.  A "sort" is the bucket arrangement of ONE scalar vector (shared by every MSM that
+  // uses those scalars: the witness feeds A1, B1, B2 and C1, prover.nim:282-302); a "lane" is one
+  // accumulate/reduce pipeline with its own stream so that independent MSMs overlap.
+  struct MsmSort {
+    Buf buf;
+    g16::MsmParams P;
+    uint32_t *count = nullptr, *cursor = nullptr, *offset = nullptr, *xoff = nullptr, *heavy = nullptr,
+             *info = nullptr, *entries = nullptr, *perm = nullptr, *ghist = nullptr, *blk_base = nullptr;
+    uint2* tiles = nullptr;
+    uint2* xseg = nullptr;
+  };
+  struct MsmLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    Buf acc;
+  };
+  MsmSort sort[2];
+  MsmLane lane[5];
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
   Buf stage_s;   // staged scalars (host-pointer API)
   Buf stage_p;   // staged points
   Buf stage_o;   // result slot
@@ -73,7 +93,9 @@ struct ProfScope {
   g16_ctx* ctx;
   bool on;
   ProfEntry e;
-  ProfScope(g16_ctx* c, const char* name) : ctx(c), on(c->profiling) {
+  hipStream_t st;
+  ProfScope(g16_ctx* c, const char* name, hipStream_t stream = nullptr)
+      : ctx(c), on(c->profiling), st(stream ? stream : c->stream) {
     if (!on) return;
     e.name = name;
     auto get = [&](hipEvent_t& ev) {
@@ -86,19 +108,21 @@ struct ProfScope {
     };
     get(e.e0);
     get(e.e1);
-    (void)hipEventRecord(e.e0, ctx->stream);
+    (void)hipEventRecord(e.e0, st);
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(e.e1, ctx->stream);
+    (void)hipEventRecord(e.e1, st);
     ctx->prof.push_back(e);
   }
 };
-#define KLAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                    \
+#define KLAUNCH_ON(ctx, stream_, name, kernel, grid, block, shmem, ...)                        \
   do {                                                                                         \
-    ProfScope ps__(ctx, name);                                                                 \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, (ctx)->stream, __VA_ARGS__);    \
+    ProfScope ps__(ctx, name, stream_);                                                        \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream_, __VA_ARGS__);          \
   } while (0)
+#define KLAUNCH(ctx, name, kernel, grid, block, shmem, ...) \
+  KLAUNCH_ON(ctx, (ctx)->stream, name, kernel, grid, block, shmem, __VA_ARGS__)
 
 
 // implemented in msm_g1.hip / msm_g2.hip / ntt.hip
@@ -107,6 +131,15 @@ int32_t g16_msm_device_g1(g16_ctx* ctx, const void* d_scalars, uint32_t flags, c
                           void* d_out_aff, void* d_out_acc, uint32_t table_c);
 int32_t g16_msm_device_g2(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
                           void* d_out_aff, void* d_out_acc, uint32_t table_c);
+// the two halves of an MSM: (1) arrange one scalar vector into buckets, (2) accumulate + reduce a point set
+// against that arrangement.  Several point sets may share one sort (same scalars, same n, same c).
+int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, uint32_t flags, size_t n,
+                     uint32_t table_c, g16_ctx::MsmSort& sort);
+int32_t g16_msm_reduce_g1(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
+                          const void* d_points, void* d_out_aff, void* d_out_acc);
+int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
+                          const void* d_points, void* d_out_aff, void* d_out_acc);
+int32_t g16_lanes_init(g16_ctx* ctx);
 int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 uint32_t g16_pick_window_g1(size_t n);

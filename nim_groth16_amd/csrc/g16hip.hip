@@ -21,7 +21,21 @@ extern "C" int32_t g16_ctx_create(int32_t device, g16_ctx** out) {
     return G16_ENODEV;
   }
   ctx->own_stream = true;
+  if (g16_lanes_init(ctx) != G16_OK) {
+    g16_ctx_destroy(ctx);
+    return G16_ENODEV;
+  }
   *out = ctx;
+  return G16_OK;
+}
+
+int32_t g16_lanes_init(g16_ctx* ctx) {
+  for (auto& l : ctx->lane) {
+    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return G16_EHIP;
+    if (hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
+  }
+  if (hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
+  if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   return G16_OK;
 }
 
@@ -29,7 +43,19 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (g16_ctx::Buf* b : {&ctx->ws, &ctx->stage_s, &ctx->stage_p, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
+  for (auto& l : ctx->lane) {
+    if (l.stream) {
+      (void)hipStreamSynchronize(l.stream);
+      (void)hipStreamDestroy(l.stream);
+    }
+    if (l.done) (void)hipEventDestroy(l.done);
+    if (l.acc.p) (void)hipFree(l.acc.p);
+  }
+  for (auto& srt : ctx->sort)
+    if (srt.buf.p) (void)hipFree(srt.buf.p);
+  if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+  if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+  for (g16_ctx::Buf* b : {&ctx->stage_s, &ctx->stage_p, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
                           &ctx->coset[0], &ctx->coset[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
                           &ctx->fb_table[1]})
     if (b->p) (void)hipFree(b->p);

@@ -16,22 +16,13 @@
 // scalars in bucket (w=0, d=1); that bucket becomes ~N/L segments handled by N/L threads.
 #pragma once
 #include "ec.cuh"
+#include "msm_params.hpp"
 
 namespace g16 {
 
 constexpr int MSM_BLOCK = 256;
 constexpr int FR_BITS = 254;
 
-struct MsmParams {
-  uint32_t n;            // number of (scalar, point) pairs
-  uint32_t c;            // window bits
-  uint32_t nwin;         // number of windows  = FR_BITS / c + 1
-  uint32_t nbuckets;     // nwin << (c-1)
-  uint32_t seg;          // L: max entries per accumulate task
-  uint32_t scalars_mont; // 1: scalars are Montgomery Fr limbs (Nim seq[Fr]); 0: canonical LE (.wtns)
-  uint32_t tables;       // 1: points array holds nwin tables [w][i] = 2^(c w) P_i (registered point set)
-  uint32_t max_extra;    // capacity of the extra-segment list
-};
 
 // canonical scalar limbs into LDS (layout [limb][thread]: conflict-free), then signed digits
 template <class EMIT>
@@ -199,6 +190,57 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_make_extra(const uint32_
   }
 }
 
+// ---- bucket order by size ------------------------------------------------------------------------------
+// Bucket sizes are ~Poisson(avg): a wave that takes 64 consecutive buckets runs as long as its largest one
+// (~70 % lane efficiency at avg 32).  perm[] lists the buckets by descending min(count, 255), so the 64
+// lanes of a wave get (nearly) equal trip counts.  Two small kernels: per-block LDS histogram + one global
+// atomic per (block, size class) to reserve a range, then ranks from LDS atomics.
+constexpr int PERM_BLOCK = 256;
+constexpr int PERM_BINS = 256;
+static __global__ void __launch_bounds__(PERM_BLOCK) perm_hist(const uint32_t* __restrict__ count, uint32_t nb,
+                                                               uint32_t* __restrict__ ghist,
+                                                               uint32_t* __restrict__ blk_base) {
+  __shared__ uint32_t h[PERM_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t b = blockIdx.x * PERM_BLOCK + threadIdx.x;
+  if (b < nb) {
+    uint32_t c = count[b];
+    atomicAdd(&h[c < PERM_BINS - 1 ? c : PERM_BINS - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t mine = h[threadIdx.x];
+  blk_base[(size_t)blockIdx.x * PERM_BINS + threadIdx.x] = mine ? atomicAdd(&ghist[threadIdx.x], mine) : 0u;
+}
+static __global__ void __launch_bounds__(PERM_BLOCK) perm_scatter(const uint32_t* __restrict__ count, uint32_t nb,
+                                                                  const uint32_t* __restrict__ ghist,
+                                                                  const uint32_t* __restrict__ blk_base,
+                                                                  uint32_t* __restrict__ perm) {
+  __shared__ uint32_t start[PERM_BINS];   // first position of size class v (descending order)
+  __shared__ uint32_t cur[PERM_BINS];
+  // suffix sums of the 256-bin histogram: start[v] = sum_{v' > v} ghist[v']
+  start[threadIdx.x] = ghist[threadIdx.x];
+  cur[threadIdx.x] = 0;
+  __syncthreads();
+  for (int d = 1; d < PERM_BINS; d <<= 1) {
+    uint32_t add = (int)threadIdx.x + d < PERM_BINS ? start[threadIdx.x + d] : 0u;
+    __syncthreads();
+    start[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t incl = start[threadIdx.x];
+  __syncthreads();
+  start[threadIdx.x] = incl - ghist[threadIdx.x];
+  __syncthreads();
+  uint32_t b = blockIdx.x * PERM_BLOCK + threadIdx.x;
+  if (b < nb) {
+    uint32_t c = count[b];
+    uint32_t v = c < PERM_BINS - 1 ? c : PERM_BINS - 1;
+    uint32_t r = atomicAdd(&cur[v], 1u);
+    perm[start[v] + blk_base[(size_t)blockIdx.x * PERM_BINS + v] + r] = b;
+  }
+}
+
 // ---- K4: bucket-segment accumulation -----------------------------------------------------------
 template <class C>
 __device__ __forceinline__ typename C::Aff load_point(const typename C::Aff* __restrict__ pts, uint32_t e) {
@@ -212,13 +254,15 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_accum(const typename C::Aff* __
                                                        const uint32_t* __restrict__ entries,
                                                        const uint32_t* __restrict__ offset,
                                                        const uint2* __restrict__ xseg,
-                                                       const uint32_t* __restrict__ info, MsmParams P,
+                                                       const uint32_t* __restrict__ info,
+                                                       const uint32_t* __restrict__ perm, MsmParams P,
                                                        typename C::Acc* __restrict__ partial) {
   uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
-  uint32_t b, s;
+  uint32_t b, s, slot;
   if (t < P.nbuckets) {
-    b = t;
+    b = perm[t];   // buckets by descending size: equal trip counts inside a wave
     s = 0;
+    slot = b;
   } else {
     uint32_t x = t - P.nbuckets;
     uint32_t nx = info[1] < P.max_extra ? info[1] : P.max_extra;
@@ -226,13 +270,14 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_accum(const typename C::Aff* __
     uint2 d = xseg[x];
     b = d.x;
     s = d.y;
+    slot = t;
   }
   uint32_t beg = offset[b], end = offset[b + 1];
   beg += s * P.seg;
   if (end > beg + P.seg) end = beg + P.seg;
   typename C::Acc acc = C::acc_inf();
   for (uint32_t j = beg; j < end; ++j) C::madd(acc, load_point<C>(points, entries[j]));
-  partial[t] = acc;
+  partial[slot] = acc;
 }
 
 // ---- K5: combine the segments of split buckets (one workgroup per heavy bucket) ---------------------

@@ -16,3 +16,11 @@ int32_t g16_fixed_base_device_g1(g16_ctx* ctx, void* d_table, bool ready, const 
   g1_aff g{Fp::one(), Fp::dbl(Fp::one())};
   return fixed_base_device<G1>(ctx, g, d_table, ready, d_s, mont, n, d_out);
 }
+int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, uint32_t flags, size_t n, uint32_t table_c,
+                     g16_ctx::MsmSort& sort) {
+  return msm_sort_device(ctx, stream, d_scalars, flags, n, table_c, sort);
+}
+int32_t g16_msm_reduce_g1(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
+                          const void* d_points, void* d_out_aff, void* d_out_acc) {
+  return msm_reduce_device<G1>(ctx, stream, acc, sort, d_points, (g1_aff*)d_out_aff, (g1_acc*)d_out_acc);
+}

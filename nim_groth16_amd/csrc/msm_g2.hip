@@ -26,3 +26,7 @@ int32_t g16_fixed_base_device_g2(g16_ctx* ctx, void* d_table, bool ready, const 
   g.y.c1 = std_fp(0x0efe500au, 0x2d02dd77u, 0xf5f40132u, 0x9f30895du, 0xf553b878u, 0xfc3c0dadu, 0xaaa86456u, 0xa623235cu);
   return fixed_base_device<G2>(ctx, g, d_table, ready, d_s, mont, n, d_out);
 }
+int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
+                          const void* d_points, void* d_out_aff, void* d_out_acc) {
+  return msm_reduce_device<G2>(ctx, stream, acc, sort, d_points, (g2_aff*)d_out_aff, (g2_acc*)d_out_acc);
+}

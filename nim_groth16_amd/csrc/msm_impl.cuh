@@ -26,40 +26,7 @@ static uint32_t pick_window(size_t n) {
   return (uint32_t)c;
 }
 
-template <class C>
-struct MsmLayout {
-  size_t count, cursor, offset, xoff, heavy, info, tiles, entries, xseg, partial, chunkR, chunkA, wsum, total;
-  MsmLayout(const MsmParams& P) {
-    size_t o = 0;
-    auto take = [&](size_t bytes) {
-      size_t r = o;
-      o += (bytes + 255) & ~size_t(255);
-      return r;
-    };
-    size_t nb = P.nbuckets;
-    count = take(nb * 4);
-    cursor = take(nb * 4);
-    offset = take((nb + 1) * 4);
-    xoff = take(nb * 4);
-    heavy = take(nb * 4);
-    info = take(64);
-    tiles = take(((nb + SCAN_TILE - 1) / SCAN_TILE) * 8);
-    entries = take((size_t)P.n * P.nwin * 4);
-    xseg = take((size_t)P.max_extra * 8);
-    partial = take((nb + P.max_extra) * sizeof(typename C::Acc));
-    size_t nchunks = nb / RED_CHUNK;
-    chunkR = take(nchunks * sizeof(typename C::Acc));
-    chunkA = take(nchunks * sizeof(typename C::Acc));
-    wsum = take((size_t)(P.nwin + 1) * sizeof(typename C::Acc));
-    total = o;
-  }
-};
-
-// d_out_aff / d_out_acc: device pointers (either may be null).  table_c != 0: d_points holds the
-// precomputed tables of a registered point set built with window size table_c.
-template <class C>
-static int32_t msm_device(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
-                          typename C::Aff* d_out_aff, typename C::Acc* d_out_acc, uint32_t table_c) {
+static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
   MsmParams P;
   P.n = (uint32_t)n;
   P.c = table_c ? table_c : pick_window(n);
@@ -71,55 +38,112 @@ static int32_t msm_device(g16_ctx* ctx, const void* d_scalars, uint32_t flags, c
   if (P.seg < 64) P.seg = 64;
   P.scalars_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
   P.max_extra = (uint32_t)(((size_t)P.n * P.nwin) / P.seg + 1);
-  MsmLayout<C> L(P);
-  int32_t rc = ensure(ctx, ctx->ws, L.total);
-  if (rc) return rc;
-  char* ws = (char*)ctx->ws.p;
-  auto* count = (uint32_t*)(ws + L.count);
-  auto* cursor = (uint32_t*)(ws + L.cursor);
-  auto* offset = (uint32_t*)(ws + L.offset);
-  auto* xoff = (uint32_t*)(ws + L.xoff);
-  auto* heavy = (uint32_t*)(ws + L.heavy);
-  auto* info = (uint32_t*)(ws + L.info);
-  auto* tiles = (uint2*)(ws + L.tiles);
-  auto* entries = (uint32_t*)(ws + L.entries);
-  auto* xseg = (uint2*)(ws + L.xseg);
-  auto* partial = (typename C::Acc*)(ws + L.partial);
-  auto* chunkR = (typename C::Acc*)(ws + L.chunkR);
-  auto* chunkA = (typename C::Acc*)(ws + L.chunkA);
-  auto* wsum = (typename C::Acc*)(ws + L.wsum);
-  const auto* scalars = (const u256*)d_scalars;
-  const auto* points = (const typename C::Aff*)d_points;
+  return P;
+}
 
-  // count + cursor are adjacent: one memset
-  HIPCHK(ctx, hipMemsetAsync(ws + L.count, 0, L.offset - L.count, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(info, 0, 64, ctx->stream));
+// ---- phase 1: scalars -> bucket arrangement (count, scan, scatter, extra-segment list) ---------------------
+static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scalars, uint32_t flags, size_t n,
+                               uint32_t table_c, g16_ctx::MsmSort& S) {
+  const MsmParams P = msm_params(n, flags, table_c);
+  S.P = P;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t r = o;
+    o += (bytes + 255) & ~size_t(255);
+    return r;
+  };
+  const size_t nb = P.nbuckets;
+  const size_t o_count = take(nb * 4), o_cursor = take(nb * 4), o_offset = take((nb + 1) * 4), o_xoff = take(nb * 4),
+               o_heavy = take(nb * 4), o_info = take(64), o_tiles = take(((nb + SCAN_TILE - 1) / SCAN_TILE) * 8),
+               o_entries = take((size_t)P.n * P.nwin * 4), o_xseg = take((size_t)P.max_extra * 8),
+               o_perm = take(nb * 4), o_ghist = take(PERM_BINS * 4),
+               o_blk = take(((nb + PERM_BLOCK - 1) / PERM_BLOCK) * PERM_BINS * 4);
+  int32_t rc = ensure(ctx, S.buf, o);
+  if (rc) return rc;
+  char* ws = (char*)S.buf.p;
+  S.count = (uint32_t*)(ws + o_count);
+  S.cursor = (uint32_t*)(ws + o_cursor);
+  S.offset = (uint32_t*)(ws + o_offset);
+  S.xoff = (uint32_t*)(ws + o_xoff);
+  S.heavy = (uint32_t*)(ws + o_heavy);
+  S.info = (uint32_t*)(ws + o_info);
+  S.tiles = (uint2*)(ws + o_tiles);
+  S.entries = (uint32_t*)(ws + o_entries);
+  S.xseg = (uint2*)(ws + o_xseg);
+  S.perm = (uint32_t*)(ws + o_perm);
+  S.ghist = (uint32_t*)(ws + o_ghist);
+  S.blk_base = (uint32_t*)(ws + o_blk);
+  const auto* scalars = (const u256*)d_scalars;
+  HIPCHK(ctx, hipMemsetAsync(ws + o_count, 0, o_offset - o_count, st));  // count + cursor are adjacent
+  HIPCHK(ctx, hipMemsetAsync(S.info, 0, 64, st));
+  HIPCHK(ctx, hipMemsetAsync(S.ghist, 0, PERM_BINS * 4, st));
   const uint32_t nblk = (P.n + MSM_BLOCK - 1) / MSM_BLOCK;
   const uint32_t ntiles = (P.nbuckets + SCAN_TILE - 1) / SCAN_TILE;
-  const bool g2 = sizeof(typename C::Aff) == 128;
-  KLAUNCH(ctx, g2 ? "msm_count_g2" : "msm_count_g1", msm_count, nblk, MSM_BLOCK, 0, scalars, P, count);
-  KLAUNCH(ctx, "msm_scan", scan_tile_sums, ntiles, SCAN_BLOCK, 0, count, P.nbuckets, P.seg, tiles);
-  KLAUNCH(ctx, "msm_scan", scan_tiles, 1, SCAN_BLOCK, 0, tiles, ntiles, info);
-  KLAUNCH(ctx, "msm_scan", scan_apply, ntiles, SCAN_BLOCK, 0, count, P.nbuckets, P.seg, tiles, offset, xoff, heavy,
-          info);
-  KLAUNCH(ctx, g2 ? "msm_scatter_g2" : "msm_scatter_g1", msm_scatter, nblk, MSM_BLOCK, 0, scalars, P, offset, cursor,
-          entries);
-  KLAUNCH(ctx, "msm_make_extra", msm_make_extra, 512, MSM_BLOCK, 0, heavy, info, offset, xoff, P.seg, P.max_extra,
-          xseg);
-  const uint32_t ntask = P.nbuckets + P.max_extra;
-  KLAUNCH(ctx, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + MSM_BLOCK - 1) / MSM_BLOCK, MSM_BLOCK, 0,
-          points, entries, offset, xseg, info, P, partial);
-  KLAUNCH(ctx, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, HEAVY_BLOCK,
-          HEAVY_BLOCK * sizeof(typename C::Acc), heavy, info, offset, xoff, P, partial);
-  const uint32_t nchunks = P.nbuckets / RED_CHUNK;
-  KLAUNCH(ctx, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>, (nchunks + MSM_BLOCK - 1) / MSM_BLOCK,
-          MSM_BLOCK, 0, partial, offset, P.nbuckets, chunkR, chunkA);
-  const uint32_t nsets = P.nwin;
-  KLAUNCH(ctx, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", msm_reduce2<C>, nsets, RED2_BLOCK,
-          RED2_BLOCK * sizeof(typename C::Acc), chunkR, chunkA, nchunks / nsets, wsum);
-  KLAUNCH(ctx, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets, P.tables ? 0u : P.c, d_out_aff, d_out_acc);
+  KLAUNCH_ON(ctx, st, "msm_count", msm_count, nblk, MSM_BLOCK, 0, scalars, P, S.count);
+  KLAUNCH_ON(ctx, st, "msm_scan", scan_tile_sums, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles);
+  KLAUNCH_ON(ctx, st, "msm_scan", scan_tiles, 1, SCAN_BLOCK, 0, S.tiles, ntiles, S.info);
+  KLAUNCH_ON(ctx, st, "msm_scan", scan_apply, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles, S.offset,
+             S.xoff, S.heavy, S.info);
+  const uint32_t pblk = (P.nbuckets + PERM_BLOCK - 1) / PERM_BLOCK;
+  KLAUNCH_ON(ctx, st, "msm_perm", perm_hist, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base);
+  KLAUNCH_ON(ctx, st, "msm_perm", perm_scatter, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base,
+             S.perm);
+  KLAUNCH_ON(ctx, st, "msm_scatter", msm_scatter, nblk, MSM_BLOCK, 0, scalars, P, S.offset, S.cursor, S.entries);
+  KLAUNCH_ON(ctx, st, "msm_make_extra", msm_make_extra, 512, MSM_BLOCK, 0, S.heavy, S.info, S.offset, S.xoff, P.seg,
+             P.max_extra, S.xseg);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
+}
+
+// ---- phase 2: accumulate + reduce one point set against a bucket arrangement --------------------------------
+// d_out_aff / d_out_acc: device pointers (either may be null).
+template <class C>
+static int32_t msm_reduce_device(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc, const g16_ctx::MsmSort& S,
+                                 const void* d_points, typename C::Aff* d_out_aff, typename C::Acc* d_out_acc) {
+  const MsmParams& P = S.P;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t r = o;
+    o += (bytes + 255) & ~size_t(255);
+    return r;
+  };
+  const size_t nchunks = P.nbuckets / RED_CHUNK;
+  const size_t o_partial = take(((size_t)P.nbuckets + P.max_extra) * sizeof(typename C::Acc)),
+               o_chunkR = take(nchunks * sizeof(typename C::Acc)), o_chunkA = take(nchunks * sizeof(typename C::Acc)),
+               o_wsum = take((size_t)(P.nwin + 1) * sizeof(typename C::Acc));
+  int32_t rc = ensure(ctx, acc, o);
+  if (rc) return rc;
+  char* ws = (char*)acc.p;
+  auto* partial = (typename C::Acc*)(ws + o_partial);
+  auto* chunkR = (typename C::Acc*)(ws + o_chunkR);
+  auto* chunkA = (typename C::Acc*)(ws + o_chunkA);
+  auto* wsum = (typename C::Acc*)(ws + o_wsum);
+  const auto* points = (const typename C::Aff*)d_points;
+  const bool g2 = sizeof(typename C::Aff) == 128;
+  const uint32_t ntask = P.nbuckets + P.max_extra;
+  KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + MSM_BLOCK - 1) / MSM_BLOCK,
+             MSM_BLOCK, 0, points, S.entries, S.offset, S.xseg, S.info, S.perm, P, partial);
+  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, HEAVY_BLOCK,
+             HEAVY_BLOCK * sizeof(typename C::Acc), S.heavy, S.info, S.offset, S.xoff, P, partial);
+  KLAUNCH_ON(ctx, st, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>,
+             (uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, partial, S.offset, P.nbuckets, chunkR,
+             chunkA);
+  const uint32_t nsets = P.nwin;
+  KLAUNCH_ON(ctx, st, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", msm_reduce2<C>, nsets, RED2_BLOCK,
+             RED2_BLOCK * sizeof(typename C::Acc), chunkR, chunkA, (uint32_t)(nchunks / nsets), wsum);
+  KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets,
+             P.tables ? 0u : P.c, d_out_aff, d_out_acc);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+// one complete MSM on the context's main stream
+template <class C>
+static int32_t msm_device(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
+                          typename C::Aff* d_out_aff, typename C::Acc* d_out_acc, uint32_t table_c) {
+  int32_t rc = msm_sort_device(ctx, ctx->stream, d_scalars, flags, n, table_c, ctx->sort[0]);
+  if (rc) return rc;
+  return msm_reduce_device<C>(ctx, ctx->stream, ctx->lane[0].acc, ctx->sort[0], d_points, d_out_aff, d_out_acc);
 }
 
 // sum of XYZZ partials -> affine (the `res += sync pending[k]` of msm.nim:117-119 across GPUs)

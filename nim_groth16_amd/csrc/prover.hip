@@ -19,9 +19,8 @@ struct g16_pkey {
   uint32_t nvars = 0, npubs = 0, log2n = 0, flavour = 1;
   // this key holds the index ranges [lo, hi) of each point set (msm.nim:105-115 chunk rule over shard_count ranks)
   uint32_t shard_index = 0, shard_count = 1;
-  size_t w_lo = 0, w_hi = 0;   // A1 / B1 / B2 : range of wires
-  size_t c_lo = 0, c_hi = 0;   // C1           : range inside witness[npubs+1 ..]
-  size_t h_lo = 0, h_hi = 0;   // H1           : range of domain indices
+  size_t w_lo = 0, w_hi = 0;   // A1 / B1 / B2 / C1 : range of wires (C1 is stored wire-aligned, see below)
+  size_t h_lo = 0, h_hi = 0;   // H1                : range of domain indices
   g16_points *A1 = nullptr, *B1 = nullptr, *B2 = nullptr, *C1 = nullptr, *H1 = nullptr;
   // CSR of the A and B matrices (zkey section 4 / ZKey.coeffs, zkey_types.nim:48-59)
   uint32_t* d_rowptr = nullptr;  // [2][n+1]
@@ -140,13 +139,17 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
     hi = (N * (k->shard_index + 1)) / k->shard_count;
   };
   range(d->nvars, k->w_lo, k->w_hi);
-  range(d->nvars - d->npubs - 1, k->c_lo, k->c_hi);
   range(n, k->h_lo, k->h_hi);
+  // pointsC1 covers wires npubs+1 .. nvars-1 (zkey_types.nim:40; zs = witness[npubs+1..], prover.nim:262-264).
+  // It is stored wire-aligned -- infinity for the npubs+1 public wires -- so that MSM(witness, C1') ==
+  // MSM(zs, C1) and all four witness MSMs share ONE bucket arrangement of the witness.
+  std::vector<unsigned char> c1pad((k->w_hi - k->w_lo) * 64, 0);
+  for (size_t wI = k->w_lo; wI < k->w_hi; ++wI)
+    if (wI > d->npubs) memcpy(&c1pad[(wI - k->w_lo) * 64], (const char*)d->pointsC1 + 64 * (wI - d->npubs - 1), 64);
   TRY(g16_points_register_g1(ctx, (const char*)d->pointsA1 + 64 * k->w_lo, k->w_hi - k->w_lo, &k->A1));
   TRY(g16_points_register_g1(ctx, (const char*)d->pointsB1 + 64 * k->w_lo, k->w_hi - k->w_lo, &k->B1));
   TRY(g16_points_register_g2(ctx, (const char*)d->pointsB2 + 128 * k->w_lo, k->w_hi - k->w_lo, &k->B2));
-  TRY(g16_points_register_g1(ctx, d->pointsC1 ? (const char*)d->pointsC1 + 64 * k->c_lo : nullptr,
-                             k->c_hi - k->c_lo, &k->C1));
+  TRY(g16_points_register_g1(ctx, c1pad.data(), k->w_hi - k->w_lo, &k->C1));
   TRY(g16_points_register_g1(ctx, (const char*)d->pointsH1 + 64 * k->h_lo, k->h_hi - k->h_lo, &k->H1));
   // CSR by counting sort on (matrix, row): A entries first, then B (sum order is irrelevant mod r)
   const g16_coeff* cf = (const g16_coeff*)d->coeffs;
@@ -245,30 +248,42 @@ extern "C" int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* k, const voi
   HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32,
                              (flags & G16_SCALARS_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                              ctx->stream));
-  // buildABC + quotient (prover.nim:244-260); replicated on every rank of a sharded proof: ~1 ms, no exchange
+  char* slots = (char*)ctx->stage_o.p;
+  hipStream_t M = ctx->stream;
+  HIPCHK(ctx, hipMemsetAsync(slots, 0, PART_BYTES, M));   // empty range -> XYZZ infinity (all zero)
+  HIPCHK(ctx, hipEventRecord(ctx->ev_a, M));              // witness resident
+  const uint32_t wflags = wit_mont ? G16_SCALARS_MONT : 0u;
+  const size_t nw = k->w_hi - k->w_lo, nh = k->h_hi - k->h_lo;
+  // The witness feeds four MSMs (A1, B1, B2, C1: prover.nim:282, 288, 294, 302): its signed-digit bucket
+  // arrangement is computed once (lane 0) and shared; the four accumulate/reduce pipelines then run on four
+  // streams so that their latency-bound tails overlap with the other pipelines' accumulation.
+  if (nw) {
+    g16_ctx::MsmLane* L = ctx->lane;
+    HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
+    if ((rc = g16_msm_sort(ctx, L[0].stream, d_w + k->w_lo, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
+    for (int i = 1; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, ctx->ev_b, 0));
+    if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, ctx->sort[0], k->B2->d_tables, nullptr, slots + PART_B2)))
+      return rc;
+    if ((rc = g16_msm_reduce_g1(ctx, L[0].stream, L[0].acc, ctx->sort[0], k->A1->d_tables, nullptr, slots + PART_A)))
+      return rc;
+    if ((rc = g16_msm_reduce_g1(ctx, L[2].stream, L[2].acc, ctx->sort[0], k->B1->d_tables, nullptr, slots + PART_B1)))
+      return rc;
+    if ((rc = g16_msm_reduce_g1(ctx, L[3].stream, L[3].acc, ctx->sort[0], k->C1->d_tables, nullptr, slots + PART_C)))
+      return rc;
+    for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipEventRecord(L[i].done, L[i].stream));
+  }
+  // buildABC + quotient (prover.nim:244-260) on the main stream, concurrently with the witness MSMs;
+  // replicated on every rank of a sharded proof (~1 ms, no exchange); then the H MSM (prover.nim:301)
   if ((rc = build_abc_device(ctx, k, d_w, wit_mont, d_abc))) return rc;
   if ((rc = g16_quotient_device(ctx, d_abc, d_abc + n, d_abc + 2 * n, k->log2n, (int)k->flavour, d_qs))) return rc;
-  // the five MSMs (prover.nim:282, 288, 294, 301, 302) over this key's index ranges
-  char* slots = (char*)ctx->stage_o.p;
-  HIPCHK(ctx, hipMemsetAsync(slots, 0, PART_BYTES, ctx->stream));   // empty range -> XYZZ infinity (all zero)
-  const uint32_t wflags = wit_mont ? G16_SCALARS_MONT : 0u;
-  struct Job {
-    const g16_points* pts;
-    const u256* scalars;
-    uint32_t flags;
-    size_t slot;
-  } jobs[5] = {{k->A1, d_w + k->w_lo, wflags, PART_A},
-               {k->B1, d_w + k->w_lo, wflags, PART_B1},
-               {k->B2, d_w + k->w_lo, wflags, PART_B2},
-               {k->H1, d_qs + k->h_lo, G16_SCALARS_MONT, PART_H},
-               {k->C1, d_w + k->npubs + 1 + k->c_lo, wflags, PART_C}};
-  for (const Job& j : jobs) {
-    if (!j.pts->n) continue;
-    rc = j.pts->group == 1
-             ? g16_msm_device_g1(ctx, j.scalars, j.flags, j.pts->d_tables, j.pts->n, nullptr, slots + j.slot, j.pts->c)
-             : g16_msm_device_g2(ctx, j.scalars, j.flags, j.pts->d_tables, j.pts->n, nullptr, slots + j.slot, j.pts->c);
-    if (rc) return rc;
+  if (nh) {
+    if ((rc = g16_msm_sort(ctx, M, d_qs + k->h_lo, G16_SCALARS_MONT, nh, k->H1->c, ctx->sort[1]))) return rc;
+    if ((rc = g16_msm_reduce_g1(ctx, M, ctx->lane[4].acc, ctx->sort[1], k->H1->d_tables, nullptr, slots + PART_H)))
+      return rc;
   }
+  if (nw)
+    for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->lane[i].done, 0));
   HIPCHK(ctx, hipMemcpyAsync(out_partials, slots, PART_BYTES,
                              (flags & G16_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
