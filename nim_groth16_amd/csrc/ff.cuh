@@ -326,12 +326,71 @@ struct Field {
     }
     return r;
   }
-  // a^(p-2)   (0 -> 0)
-  static FF_HD T inv(const T& a) {
+  // a^(p-2)   (0 -> 0): Fermat inversion, ~380 modmuls
+  static FF_HD T inv_fermat(const T& a) {
     uint32_t e[8];
     e[0] = PR::P0 - 2; e[1] = PR::P1; e[2] = PR::P2; e[3] = PR::P3;
     e[4] = PR::P4; e[5] = PR::P5; e[6] = PR::P6; e[7] = PR::P7;
     return pow(a, e);
+  }
+  // ---- helpers for the binary extended Euclid below (plain 256-bit integers) ----
+  static FF_HD bool geq(const T& a, const T& b) {
+    T t;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.v[i] = subc(a.v[i], b.v[i], bw);
+    return bw == 0;
+  }
+  static FF_HD T raw_sub(const T& a, const T& b) {
+    T t;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.v[i] = subc(a.v[i], b.v[i], bw);
+    return t;
+  }
+  static FF_HD T shr1(const T& a) {
+    T r;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.v[i] = (a.v[i] >> 1) | (a.v[i + 1] << 31);
+    r.v[7] = a.v[7] >> 1;
+    return r;
+  }
+  static FF_HD bool is_one_raw(const T& a) {
+    uint32_t o = a.v[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) o |= a.v[i];
+    return o == 0;
+  }
+  static FF_HD T r3() {   // R^3 mod p = R2 * R2 / R * ... computed once per call: mul(R2, R2) = R^3
+    return mul(r2(), r2());
+  }
+  // Modular inverse by the binary extended Euclidean algorithm (vartime; ~2*254 shift/subtract steps of
+  // 8-limb integer ops, ~20x cheaper than Fermat on one lane).  In: a*R, out: a^-1 * R.  0 -> 0.
+  static FF_HD T inv(const T& a) {
+    if (is_zero(a)) return a;
+    T u = a, v, x1 = zero(), x2 = zero();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v.v[i] = Pi(i);
+    x1.v[0] = 1;   // invariants: x1 * a == u, x2 * a == v (mod p)
+    while (!is_one_raw(u) && !is_one_raw(v)) {
+      while ((u.v[0] & 1) == 0) {
+        u = shr1(u);
+        x1 = div2(x1);
+      }
+      while ((v.v[0] & 1) == 0) {
+        v = shr1(v);
+        x2 = div2(x2);
+      }
+      if (geq(u, v)) {
+        u = raw_sub(u, v);
+        x1 = sub(x1, x2);
+      } else {
+        v = raw_sub(v, u);
+        x2 = sub(x2, x1);
+      }
+    }
+    // x = (aR)^-1 = a^-1 R^-1 as an integer; one Montgomery product with R^3 gives a^-1 R
+    return mul(is_one_raw(u) ? x1 : x2, r3());
   }
   static FF_HD T mul_small(const T& a, uint32_t k) {  // k in {2,3,4,8}: via doublings/adds
     T r = a;

@@ -75,6 +75,95 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __re
   });
 }
 
+// ---- two-level partition sort (no global atomics) -------------------------------------------------------
+// Global atomics execute at the memory side on MI355X (~26 G/s measured for scattered 4-byte adds), which
+// made the histogram + scatter above cost 1.6 ms per 2^20 scalars.  Here the (window, bucket) key is split
+// into a partition id (window, high bucket bits; <= 4096 partitions) and <= 8 low bits:
+//   part_pass<false>  per tile of 4096 scalars: LDS histogram over partitions -> tile_hist[part][tile]
+//   (exclusive scan of tile_hist, partition-major = final bucket order)
+//   part_pass<true>   recompute digits; rank inside (tile, partition) from LDS atomics; tmp entry =
+//                     low bits | sign<<8 | scalar index<<9
+//   bucket_sort       one workgroup per partition: LDS histogram over the low bits -> count[], offset[],
+//                     then placement of the final entries in bucket order
+constexpr int PART_BLOCK = 256;
+constexpr int PART_PER_THREAD = 16;
+constexpr int PART_TILE = PART_BLOCK * PART_PER_THREAD;  // scalars per workgroup
+constexpr int PART_MAX = 4096;                           // max partitions (LDS histogram)
+
+template <bool SCATTER>
+static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __restrict__ scalars, MsmParams P,
+                                                               uint32_t lo_bits, uint32_t nparts, uint32_t ntiles,
+                                                               uint32_t* __restrict__ tile_hist,
+                                                               uint32_t* __restrict__ tmp) {
+  __shared__ uint32_t limbs[9 * MSM_BLOCK];
+  __shared__ uint32_t hist[PART_MAX];
+  const uint32_t tile = blockIdx.x;
+  for (uint32_t p = threadIdx.x; p < nparts; p += PART_BLOCK)
+    hist[p] = SCATTER ? tile_hist[(size_t)p * ntiles + tile] : 0u;   // SCATTER: exclusive base of (part, tile)
+  __syncthreads();
+  const uint32_t hi_bits = P.c - 1 - lo_bits, lo_mask = (1u << lo_bits) - 1;
+  for (uint32_t r = 0; r < PART_PER_THREAD; ++r) {
+    uint32_t i = tile * PART_TILE + r * PART_BLOCK + threadIdx.x;
+    if (i < P.n) {
+      msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t neg) {
+        uint32_t part = (w << hi_bits) | (k >> lo_bits);
+        uint32_t pos = atomicAdd(&hist[part], 1u);
+        if (SCATTER) tmp[pos] = (k & lo_mask) | (neg << 8) | (i << 9);
+      });
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < nparts; p += PART_BLOCK) tile_hist[(size_t)p * ntiles + tile] = hist[p];
+  }
+}
+
+static __global__ void __launch_bounds__(256) bucket_sort(const uint32_t* __restrict__ tmp,
+                                                          const uint32_t* __restrict__ part_base, uint32_t ntiles,
+                                                          uint32_t nparts, const uint32_t* __restrict__ total,
+                                                          MsmParams P, uint32_t lo_bits,
+                                                          uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
+                                                          uint32_t* __restrict__ entries) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t cur[256];
+  const uint32_t part = blockIdx.x, tid = threadIdx.x;
+  const uint32_t start = part_base[(size_t)part * ntiles];
+  const uint32_t end = part + 1 < nparts ? part_base[(size_t)(part + 1) * ntiles] : total[0];
+  hist[tid] = 0;
+  __syncthreads();
+  for (uint32_t j = start + tid; j < end; j += 256) atomicAdd(&hist[tmp[j] & 0xffu], 1u);
+  __syncthreads();
+  // exclusive scan of the 256 counters (Hillis-Steele in LDS)
+  uint32_t mine = hist[tid];
+  cur[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t add = (int)tid >= d ? cur[tid - d] : 0u;
+    __syncthreads();
+    cur[tid] += add;
+    __syncthreads();
+  }
+  const uint32_t excl = cur[tid] - mine;
+  __syncthreads();
+  cur[tid] = start + excl;
+  const uint32_t hi_bits = P.c - 1 - lo_bits;
+  const uint32_t w = part >> hi_bits, hi = part & ((1u << hi_bits) - 1);
+  if (tid < (1u << lo_bits)) {
+    uint32_t b = (w << (P.c - 1)) + (hi << lo_bits) + tid;
+    count[b] = mine;
+    offset[b] = start + excl;
+  }
+  if (part == nparts - 1 && tid == 0) offset[P.nbuckets] = end;
+  __syncthreads();
+  const uint32_t base_idx = P.tables ? w * P.n : 0u;
+  for (uint32_t j = start + tid; j < end; j += 256) {
+    uint32_t e = tmp[j];
+    uint32_t pos = atomicAdd(&cur[e & 0xffu], 1u);
+    entries[pos] = (base_idx + (e >> 9)) | (((e >> 8) & 1u) << 31);
+  }
+}
+
+// plain exclusive scan of a u32 array in place (three launches, reuses the tile machinery below)
 // ---- three-phase exclusive scan over the bucket histogram ------------------------------------------
 // produces offset[b] = sum_{b'<b} count[b'], xoff[b] = sum_{b'<b} extra(b') with
 // extra(b) = max(ceil(count/L) - 1, 0), and appends buckets with extra(b) > 0 to the heavy list.
@@ -173,6 +262,36 @@ static __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply(const uint32_t* 
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) offset[nb] = o;
 }
 
+// in-place exclusive scan of a plain u32 array (used for tile_hist): same three phases
+static __global__ void __launch_bounds__(SCAN_BLOCK) scan1_tile_sums(const uint32_t* __restrict__ v, uint32_t n,
+                                                                     uint2* __restrict__ tile_sum) {
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint2 s = make_uint2(0, 0);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) s.x += base + j < n ? v[base + j] : 0u;
+  uint2 tot;
+  block_excl_scan2(s, &tot);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+static __global__ void __launch_bounds__(SCAN_BLOCK) scan1_apply(uint32_t* __restrict__ v, uint32_t n,
+                                                                 const uint2* __restrict__ tile_sum) {
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t x[SCAN_ITEMS];
+  uint2 s = make_uint2(0, 0);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    x[j] = base + j < n ? v[base + j] : 0u;
+    s.x += x[j];
+  }
+  uint2 ex = block_excl_scan2(s, nullptr);
+  uint32_t o = tile_sum[blockIdx.x].x + ex.x;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j < n) v[base + j] = o;
+    o += x[j];
+  }
+}
+
 // extra-segment descriptors: xseg[xoff[b] + s - 1] = (b, s) for s = 1..extra(b)
 static __global__ void __launch_bounds__(MSM_BLOCK) msm_make_extra(const uint32_t* __restrict__ heavy,
                                                             const uint32_t* __restrict__ info,
@@ -249,8 +368,10 @@ __device__ __forceinline__ typename C::Aff load_point(const typename C::Aff* __r
   return p;
 }
 
+// occupancy target: G1 fits 4 waves/SIMD (<=128 VGPRs); G2 needs ~260 registers unconstrained, which would
+// drop it to 1 wave/SIMD -- bound it to 256 (2 waves/SIMD)
 template <class C>
-__global__ void __launch_bounds__(MSM_BLOCK) msm_accum(const typename C::Aff* __restrict__ points,
+__global__ void __launch_bounds__(MSM_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : 2) msm_accum(const typename C::Aff* __restrict__ points,
                                                        const uint32_t* __restrict__ entries,
                                                        const uint32_t* __restrict__ offset,
                                                        const uint2* __restrict__ xseg,

@@ -58,6 +58,15 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
                o_entries = take((size_t)P.n * P.nwin * 4), o_xseg = take((size_t)P.max_extra * 8),
                o_perm = take(nb * 4), o_ghist = take(PERM_BINS * 4),
                o_blk = take(((nb + PERM_BLOCK - 1) / PERM_BLOCK) * PERM_BINS * 4);
+  // partition sort (see msm.cuh): low bits <= 8, partitions = nwin << hi_bits
+  const uint32_t lo_bits = P.c - 1 < 8 ? P.c - 1 : 8;
+  const uint32_t nparts = P.nwin << (P.c - 1 - lo_bits);
+  const uint32_t ptiles = (P.n + PART_TILE - 1) / PART_TILE;
+  const char* env_sort = getenv("G16_MSM_SORT");
+  const bool use_part = nparts <= PART_MAX && P.n < (1u << 23) && !(env_sort && env_sort[0] == 'a');
+  const size_t nth = (size_t)nparts * ptiles;
+  const size_t o_thist = take(use_part ? nth * 4 : 4), o_tmp = take(use_part ? (size_t)P.n * P.nwin * 4 : 4),
+               o_tiles2 = take(((nth + SCAN_TILE - 1) / SCAN_TILE) * 8 + 8);
   int32_t rc = ensure(ctx, S.buf, o);
   if (rc) return rc;
   char* ws = (char*)S.buf.p;
@@ -73,13 +82,29 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   S.perm = (uint32_t*)(ws + o_perm);
   S.ghist = (uint32_t*)(ws + o_ghist);
   S.blk_base = (uint32_t*)(ws + o_blk);
+  S.tile_hist = (uint32_t*)(ws + o_thist);
+  S.tmp = (uint32_t*)(ws + o_tmp);
+  S.tiles2 = (uint2*)(ws + o_tiles2);
   const auto* scalars = (const u256*)d_scalars;
   HIPCHK(ctx, hipMemsetAsync(ws + o_count, 0, o_offset - o_count, st));  // count + cursor are adjacent
   HIPCHK(ctx, hipMemsetAsync(S.info, 0, 64, st));
   HIPCHK(ctx, hipMemsetAsync(S.ghist, 0, PERM_BINS * 4, st));
   const uint32_t nblk = (P.n + MSM_BLOCK - 1) / MSM_BLOCK;
   const uint32_t ntiles = (P.nbuckets + SCAN_TILE - 1) / SCAN_TILE;
-  KLAUNCH_ON(ctx, st, "msm_count", msm_count, nblk, MSM_BLOCK, 0, scalars, P, S.count);
+  if (use_part) {
+    const uint32_t nt2 = (uint32_t)((nth + SCAN_TILE - 1) / SCAN_TILE);
+    KLAUNCH_ON(ctx, st, "msm_part_count", part_pass<false>, ptiles, PART_BLOCK, 0, scalars, P, lo_bits, nparts, ptiles,
+               S.tile_hist, S.tmp);
+    KLAUNCH_ON(ctx, st, "msm_scan", scan1_tile_sums, nt2, SCAN_BLOCK, 0, S.tile_hist, (uint32_t)nth, S.tiles2);
+    KLAUNCH_ON(ctx, st, "msm_scan", scan_tiles, 1, SCAN_BLOCK, 0, S.tiles2, nt2, S.info + 8);  // total -> info[8]
+    KLAUNCH_ON(ctx, st, "msm_scan", scan1_apply, nt2, SCAN_BLOCK, 0, S.tile_hist, (uint32_t)nth, S.tiles2);
+    KLAUNCH_ON(ctx, st, "msm_part_scatter", part_pass<true>, ptiles, PART_BLOCK, 0, scalars, P, lo_bits, nparts,
+               ptiles, S.tile_hist, S.tmp);
+    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_sort, nparts, 256, 0, S.tmp, S.tile_hist, ptiles, nparts, S.info + 8,
+               P, lo_bits, S.count, S.offset, S.entries);
+  } else {
+    KLAUNCH_ON(ctx, st, "msm_count", msm_count, nblk, MSM_BLOCK, 0, scalars, P, S.count);
+  }
   KLAUNCH_ON(ctx, st, "msm_scan", scan_tile_sums, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles);
   KLAUNCH_ON(ctx, st, "msm_scan", scan_tiles, 1, SCAN_BLOCK, 0, S.tiles, ntiles, S.info);
   KLAUNCH_ON(ctx, st, "msm_scan", scan_apply, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles, S.offset,
@@ -88,7 +113,8 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   KLAUNCH_ON(ctx, st, "msm_perm", perm_hist, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base);
   KLAUNCH_ON(ctx, st, "msm_perm", perm_scatter, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base,
              S.perm);
-  KLAUNCH_ON(ctx, st, "msm_scatter", msm_scatter, nblk, MSM_BLOCK, 0, scalars, P, S.offset, S.cursor, S.entries);
+  if (!use_part)
+    KLAUNCH_ON(ctx, st, "msm_scatter", msm_scatter, nblk, MSM_BLOCK, 0, scalars, P, S.offset, S.cursor, S.entries);
   KLAUNCH_ON(ctx, st, "msm_make_extra", msm_make_extra, 512, MSM_BLOCK, 0, S.heavy, S.info, S.offset, S.xoff, P.seg,
              P.max_extra, S.xseg);
   HIPCHK(ctx, hipGetLastError());

@@ -127,3 +127,14 @@ def test_msm_registered_empty(ctx):
     h = ctx.register_points(1, b"", 0)
     assert ctx.msm_points(h, b"") == INF[1]
     h.release()
+
+
+def test_msm_atomic_sort_path_still_agrees(ctx, orc, monkeypatch):
+    """the global-atomic histogram/scatter path (used when the partition sort does not apply) stays correct"""
+    n = 5000
+    ks, pts = I.points_with_logs(orc, 1, n, seed=81)
+    sc = I.circom_like_scalars(n, 82)
+    want = I.expected_from_logs(1, sc, ks)
+    assert ctx.msm(1, I.fr_mont_bytes(sc), pts, n) == want
+    monkeypatch.setenv("G16_MSM_SORT", "atomic")
+    assert ctx.msm(1, I.fr_mont_bytes(sc), pts, n) == want
