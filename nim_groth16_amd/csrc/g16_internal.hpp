@@ -35,7 +35,9 @@ struct g16_ctx {
     Buf buf;
     g16::MsmParams P;
     uint32_t *count = nullptr, *cursor = nullptr, *offset = nullptr, *xoff = nullptr, *heavy = nullptr,
-             *info = nullptr, *entries = nullptr, *perm = nullptr, *ghist = nullptr, *blk_base = nullptr, *tile_hist = nullptr, *tmp = nullptr;
+             *info = nullptr, *entries = nullptr, *perm = nullptr, *ghist = nullptr, *blk_base = nullptr, *tile_hist = nullptr;
+    uint2* tmp = nullptr;
+    uint32_t* slice_hist = nullptr;
     uint2* tiles2 = nullptr;
     uint2* tiles = nullptr;
     uint2* xseg = nullptr;

@@ -55,7 +55,9 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_count(const u256* __rest
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= P.n) return;
   const uint32_t bshift = P.c - 1;
-  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t) { atomicAdd(&count[(w << bshift) + k], 1u); });
+  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t) {
+    atomicAdd(&count[(P.tables ? 0u : (w << bshift)) + k], 1u);
+  });
 }
 
 static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __restrict__ scalars, MsmParams P,
@@ -67,7 +69,7 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __re
   if (i >= P.n) return;
   const uint32_t bshift = P.c - 1;
   msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t neg) {
-    uint32_t b = (w << bshift) + k;
+    uint32_t b = (P.tables ? 0u : (w << bshift)) + k;
     uint32_t pos = offset[b] + atomicAdd(&cursor[b], 1u);
     // entry = point index (table-major when tables are used) | sign in bit 31
     uint32_t pidx = P.tables ? (w * P.n + i) : i;
@@ -82,19 +84,43 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __re
 //   part_pass<false>  per tile of 4096 scalars: LDS histogram over partitions -> tile_hist[part][tile]
 //   (exclusive scan of tile_hist, partition-major = final bucket order)
 //   part_pass<true>   recompute digits; rank inside (tile, partition) from LDS atomics; tmp entry =
-//                     low bits | sign<<8 | scalar index<<9
-//   bucket_sort       one workgroup per partition: LDS histogram over the low bits -> count[], offset[],
+//                     { low bits | sign<<8 , point index (table-major for registered sets) }
+//   bucket_hist/place 8 workgroups per partition: LDS histograms over the low bits -> count[], offset[],
 //                     then placement of the final entries in bucket order
+// LDS counter increment that returns the old value, robust against one hot key per wave: skewed scalars
+// (a circom witness is ~30 % ones; a short top window maps every scalar to a handful of buckets) would
+// otherwise serialise 64 same-address LDS atomics per wave-instruction.  If more than 8 lanes of the wave
+// carry the first active lane's key, that group issues ONE atomic and ranks itself by prefix popcount.
+__device__ __forceinline__ uint32_t lds_rank_add(uint32_t* ctr, uint32_t key) {
+  const uint32_t leader = __builtin_amdgcn_readfirstlane(key);
+  const unsigned long long m = __ballot(key == leader);
+  if (__popcll(m) > 8) {
+    uint32_t r = 0;
+    if (key == leader) {
+      const uint32_t lane = threadIdx.x & 63;
+      const uint32_t before = __popcll(m & ((1ull << lane) - 1));
+      uint32_t base = 0;
+      if (before == 0) base = atomicAdd(&ctr[leader], (uint32_t)__popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1, 64);
+      r = base + before;
+    } else {
+      r = atomicAdd(&ctr[key], 1u);
+    }
+    return r;
+  }
+  return atomicAdd(&ctr[key], 1u);
+}
+
 constexpr int PART_BLOCK = 256;
 constexpr int PART_PER_THREAD = 16;
 constexpr int PART_TILE = PART_BLOCK * PART_PER_THREAD;  // scalars per workgroup
-constexpr int PART_MAX = 4096;                           // max partitions (LDS histogram)
+constexpr int PART_MAX = 8192;                           // max partitions (LDS histogram, 32 KB)
 
 template <bool SCATTER>
 static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __restrict__ scalars, MsmParams P,
                                                                uint32_t lo_bits, uint32_t nparts, uint32_t ntiles,
                                                                uint32_t* __restrict__ tile_hist,
-                                                               uint32_t* __restrict__ tmp) {
+                                                               uint2* __restrict__ tmp) {
   __shared__ uint32_t limbs[9 * MSM_BLOCK];
   __shared__ uint32_t hist[PART_MAX];
   const uint32_t tile = blockIdx.x;
@@ -106,9 +132,9 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
     uint32_t i = tile * PART_TILE + r * PART_BLOCK + threadIdx.x;
     if (i < P.n) {
       msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t neg) {
-        uint32_t part = (w << hi_bits) | (k >> lo_bits);
-        uint32_t pos = atomicAdd(&hist[part], 1u);
-        if (SCATTER) tmp[pos] = (k & lo_mask) | (neg << 8) | (i << 9);
+        uint32_t part = (P.tables ? 0u : (w << hi_bits)) | (k >> lo_bits);
+        uint32_t pos = lds_rank_add(hist, part);
+        if (SCATTER) tmp[pos] = make_uint2((k & lo_mask) | (neg << 8), P.tables ? w * P.n + i : i);
       });
     }
   }
@@ -118,23 +144,51 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
   }
 }
 
-static __global__ void __launch_bounds__(256) bucket_sort(const uint32_t* __restrict__ tmp,
+// A partition can be arbitrarily large (skewed scalars), so each one is cut into BS_SPLIT slices handled by
+// separate workgroups: bucket_hist counts the low bits per slice, bucket_place derives count[]/offset[] from
+// the slice histograms and writes the final entries.
+constexpr int BS_SPLIT = 8;
+__device__ __forceinline__ void bs_slice(uint32_t start, uint32_t end, uint32_t q, uint32_t& lo, uint32_t& hi) {
+  const uint32_t len = end - start;
+  lo = start + (uint32_t)(((uint64_t)len * q) / BS_SPLIT);
+  hi = start + (uint32_t)(((uint64_t)len * (q + 1)) / BS_SPLIT);
+}
+static __global__ void __launch_bounds__(256) bucket_hist(const uint2* __restrict__ tmp,
                                                           const uint32_t* __restrict__ part_base, uint32_t ntiles,
                                                           uint32_t nparts, const uint32_t* __restrict__ total,
-                                                          MsmParams P, uint32_t lo_bits,
-                                                          uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
-                                                          uint32_t* __restrict__ entries) {
+                                                          uint32_t* __restrict__ slice_hist) {
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t cur[256];
-  const uint32_t part = blockIdx.x, tid = threadIdx.x;
+  const uint32_t part = blockIdx.x / BS_SPLIT, q = blockIdx.x % BS_SPLIT, tid = threadIdx.x;
   const uint32_t start = part_base[(size_t)part * ntiles];
   const uint32_t end = part + 1 < nparts ? part_base[(size_t)(part + 1) * ntiles] : total[0];
+  uint32_t lo, hi;
+  bs_slice(start, end, q, lo, hi);
   hist[tid] = 0;
   __syncthreads();
-  for (uint32_t j = start + tid; j < end; j += 256) atomicAdd(&hist[tmp[j] & 0xffu], 1u);
+  for (uint32_t j = lo + tid; j < hi; j += 256) lds_rank_add(hist, tmp[j].x & 0xffu);
   __syncthreads();
-  // exclusive scan of the 256 counters (Hillis-Steele in LDS)
-  uint32_t mine = hist[tid];
+  slice_hist[(size_t)blockIdx.x * 256 + tid] = hist[tid];
+}
+static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restrict__ tmp,
+                                                           const uint32_t* __restrict__ part_base, uint32_t ntiles,
+                                                           uint32_t nparts, const uint32_t* __restrict__ total,
+                                                           const uint32_t* __restrict__ slice_hist, MsmParams P,
+                                                           uint32_t lo_bits, uint32_t* __restrict__ count,
+                                                           uint32_t* __restrict__ offset,
+                                                           uint32_t* __restrict__ entries) {
+  __shared__ uint32_t cur[256];
+  const uint32_t part = blockIdx.x / BS_SPLIT, q = blockIdx.x % BS_SPLIT, tid = threadIdx.x;
+  const uint32_t start = part_base[(size_t)part * ntiles];
+  const uint32_t end = part + 1 < nparts ? part_base[(size_t)(part + 1) * ntiles] : total[0];
+  // bucket totals over all slices, and the part of each bucket that belongs to earlier slices
+  uint32_t mine = 0, before = 0;
+#pragma unroll
+  for (int k = 0; k < BS_SPLIT; ++k) {
+    uint32_t h = slice_hist[((size_t)part * BS_SPLIT + k) * 256 + tid];
+    mine += h;
+    if ((uint32_t)k < q) before += h;
+  }
+  // exclusive scan of the 256 bucket totals (Hillis-Steele in LDS)
   cur[tid] = mine;
   __syncthreads();
   for (int d = 1; d < 256; d <<= 1) {
@@ -145,21 +199,23 @@ static __global__ void __launch_bounds__(256) bucket_sort(const uint32_t* __rest
   }
   const uint32_t excl = cur[tid] - mine;
   __syncthreads();
-  cur[tid] = start + excl;
-  const uint32_t hi_bits = P.c - 1 - lo_bits;
-  const uint32_t w = part >> hi_bits, hi = part & ((1u << hi_bits) - 1);
-  if (tid < (1u << lo_bits)) {
-    uint32_t b = (w << (P.c - 1)) + (hi << lo_bits) + tid;
-    count[b] = mine;
-    offset[b] = start + excl;
+  cur[tid] = start + excl + before;
+  if (q == 0) {
+    // bucket index of (part, low bits): partitions are numbered in bucket order in both modes
+    if (tid < (1u << lo_bits)) {
+      uint32_t b = (part << lo_bits) + tid;
+      count[b] = mine;
+      offset[b] = start + excl;
+    }
+    if (part == nparts - 1 && tid == 0) offset[P.nbuckets] = end;
   }
-  if (part == nparts - 1 && tid == 0) offset[P.nbuckets] = end;
   __syncthreads();
-  const uint32_t base_idx = P.tables ? w * P.n : 0u;
-  for (uint32_t j = start + tid; j < end; j += 256) {
-    uint32_t e = tmp[j];
-    uint32_t pos = atomicAdd(&cur[e & 0xffu], 1u);
-    entries[pos] = (base_idx + (e >> 9)) | (((e >> 8) & 1u) << 31);
+  uint32_t lo, hi;
+  bs_slice(start, end, q, lo, hi);
+  for (uint32_t j = lo + tid; j < hi; j += 256) {
+    uint2 e = tmp[j];
+    uint32_t pos = lds_rank_add(cur, e.x & 0xffu);
+    entries[pos] = e.y | (((e.x >> 8) & 1u) << 31);
   }
 }
 
@@ -172,6 +228,9 @@ constexpr int SCAN_ITEMS = 8;                       // per thread
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;  // 2048 buckets per workgroup
 
 __device__ __forceinline__ uint32_t extra_segs(uint32_t cnt, uint32_t L) { return cnt > L ? (cnt - 1) / L : 0u; }
+// split buckets with at least this many extra segments are combined by a workgroup (msm_heavy), the others by
+// one thread each (msm_heavy_small)
+constexpr uint32_t HEAVY_MIN = 12;
 
 __device__ __forceinline__ uint2 block_excl_scan2(uint2 v, uint2* total) {
   // exclusive scan of (x,y) across SCAN_BLOCK threads: wave shuffles + LDS across the 4 waves
@@ -254,7 +313,7 @@ static __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply(const uint32_t* 
       offset[b] = o;
       xoff[b] = x;
       uint32_t e = extra_segs(cnt[j], L);
-      if (e) heavy[atomicAdd(&info[2], 1u)] = b;
+      if (e) heavy[atomicAdd(&info[2], 1u)] = b;   // every split bucket: msm_make_extra lists its segments
       o += cnt[j];
       x += e;
     }
@@ -378,20 +437,21 @@ __global__ void __launch_bounds__(MSM_BLOCK, sizeof(typename C::Aff) == 64 ? 4 :
                                                        const uint32_t* __restrict__ info,
                                                        const uint32_t* __restrict__ perm, MsmParams P,
                                                        typename C::Acc* __restrict__ partial) {
-  uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  // task order = dispatch order: the extra segments of split buckets (the longest tasks, L entries each)
+  // first, then the buckets by descending size, so that no long task is left for the tail of the launch
+  const uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  const uint32_t nx = info[1] < P.max_extra ? info[1] : P.max_extra;
   uint32_t b, s, slot;
-  if (t < P.nbuckets) {
-    b = perm[t];   // buckets by descending size: equal trip counts inside a wave
-    s = 0;
-    slot = b;
-  } else {
-    uint32_t x = t - P.nbuckets;
-    uint32_t nx = info[1] < P.max_extra ? info[1] : P.max_extra;
-    if (x >= nx) return;
-    uint2 d = xseg[x];
+  if (t < nx) {
+    uint2 d = xseg[t];
     b = d.x;
     s = d.y;
-    slot = t;
+    slot = P.nbuckets + t;
+  } else {
+    if (t - nx >= P.nbuckets) return;
+    b = perm[t - nx];   // equal trip counts inside a wave
+    s = 0;
+    slot = b;
   }
   uint32_t beg = offset[b], end = offset[b + 1];
   beg += s * P.seg;
@@ -433,6 +493,7 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) msm_heavy(const uint32_t* __restr
   for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
     uint32_t b = heavy[h];
     uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
+    if (e < HEAVY_MIN) continue;   // left to msm_heavy_small (uniform per workgroup: no barrier is skipped unevenly)
     typename C::Acc acc = C::acc_inf();
     // segment 0 lives at partial[b]; segments 1..e at partial[nbuckets + x0 + s - 1]
     for (uint32_t s = threadIdx.x; s <= e; s += HEAVY_BLOCK) {
@@ -441,6 +502,24 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) msm_heavy(const uint32_t* __restr
     }
     typename C::Acc r = block_sum<C, HEAVY_BLOCK>(acc, sh);
     if (threadIdx.x == 0) partial[b] = r;
+  }
+}
+
+// split buckets with only a few extra segments: one thread per bucket adds them into partial[b]
+template <class C>
+__global__ void __launch_bounds__(MSM_BLOCK) msm_heavy_small(const uint32_t* __restrict__ heavy,
+                                                             const uint32_t* __restrict__ info,
+                                                             const uint32_t* __restrict__ offset,
+                                                             const uint32_t* __restrict__ xoff, MsmParams P,
+                                                             typename C::Acc* __restrict__ partial) {
+  const uint32_t nheavy = info[2];
+  for (uint32_t h = blockIdx.x * MSM_BLOCK + threadIdx.x; h < nheavy; h += gridDim.x * MSM_BLOCK) {
+    const uint32_t b = heavy[h];
+    const uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
+    if (e >= HEAVY_MIN) continue;
+    typename C::Acc acc = partial[b];
+    for (uint32_t k = 0; k < e; ++k) C::add(acc, partial[P.nbuckets + x0 + k]);
+    partial[b] = acc;
   }
 }
 
@@ -472,7 +551,8 @@ template <class C>
 __global__ void __launch_bounds__(RED2_BLOCK) msm_reduce2(const typename C::Acc* __restrict__ chunkR,
                                                           const typename C::Acc* __restrict__ chunkA,
                                                           uint32_t chunks_per_window,
-                                                          typename C::Acc* __restrict__ window_sum) {
+                                                          typename C::Acc* __restrict__ window_sum,
+                                                          typename C::Acc* __restrict__ window_tot) {
   extern __shared__ __align__(16) unsigned char smem[];
   typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
   const uint32_t w = blockIdx.x, M = chunks_per_window;
@@ -509,6 +589,7 @@ __global__ void __launch_bounds__(RED2_BLOCK) msm_reduce2(const typename C::Acc*
   // counted once for every chunk index below its slice start.  Using suffix sums:
   //   sum_t lo_t run_t = per * sum_{t>=1} suffix_incl(t)        (lo_t = t * per)
   typename C::Acc suf = (threadIdx.x >= 1 && lo < M) ? incl : C::acc_inf();
+  if (threadIdx.x == 0) window_tot[w] = incl;   // sum of every bucket of this set
   __syncthreads();
   typename C::Acc sufsum = block_sum<C, RED2_BLOCK>(suf, sh);
   typename C::Acc wtot = block_sum<C, RED2_BLOCK>(wsum, sh);
@@ -537,6 +618,33 @@ __global__ void msm_fold(const typename C::Acc* __restrict__ window_sum, uint32_
   }
   if (out_acc) *out_acc = r;
   if (out_aff) *out_aff = C::to_affine(r);
+}
+
+// ---- K7': fold for the merged bucket set of a registered point set ------------------------------------
+// The 2^(c-1) buckets were reduced in `nsets` slices of Ks = 2^log2ks buckets with slice-local weights
+// 1..Ks; slice v starts at bucket v*Ks, so   S = sum_v S_v + Ks * sum_v v * Tot_v .
+// One wave: lane v forms v*Tot_v, LDS trees add the lanes, lane 0 applies the log2(Ks) doublings.
+template <class C>
+__global__ void __launch_bounds__(64) msm_fold_merged(const typename C::Acc* __restrict__ set_sum,
+                                                      const typename C::Acc* __restrict__ set_tot, uint32_t nsets,
+                                                      uint32_t log2ks, typename C::Aff* __restrict__ out_aff,
+                                                      typename C::Acc* __restrict__ out_acc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
+  const uint32_t v = threadIdx.x;
+  typename C::Acc x = C::acc_inf(), y = C::acc_inf();
+  if (v < nsets) {
+    y = set_sum[v];
+    if (v) x = C::mul_small(set_tot[v], v);
+  }
+  typename C::Acc xs = block_sum<C, 64>(x, sh);
+  typename C::Acc ys = block_sum<C, 64>(y, sh);
+  if (v == 0) {
+    for (uint32_t i = 0; i < log2ks; ++i) xs = C::dbl(xs);
+    C::add(xs, ys);
+    if (out_acc) *out_acc = xs;
+    if (out_aff) *out_aff = C::to_affine(xs);
+  }
 }
 
 // ---- registration-time precomputation:  table[w][i] = 2^(c w) * P_i  (affine), w = 0..nwin-1 ---------

@@ -9,7 +9,7 @@ int32_t g16_sum_partials_device_g2(g16_ctx* ctx, const void* parts, uint32_t cou
 int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
   return precompute_device<G2>(ctx, d_points, n, c, d_tables);
 }
-uint32_t g16_pick_window_g2(size_t n) { return pick_window(n); }
+uint32_t g16_pick_window_g2(size_t n) { return pick_table_window(n); }
 int32_t g16_fixed_base_device_g2(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
                                  void* d_out) {
   // gen2 (curves.nim:115-121), standard form -> Montgomery

@@ -12,19 +12,33 @@ static uint32_t floor_log2(size_t x) {
   return k;
 }
 
-// window size: ~32 entries per bucket on average keeps bucket-accumulation (n*nwin madds) and bucket
-// reduction (2*nbuckets adds) balanced; RED_CHUNK needs 2^(c-1) >= 16.
-static uint32_t pick_window(size_t n) {
-  int c = (int)floor_log2(n ? n : 1) - 4;
-  if (c < 5) c = 5;
-  if (c > 16) c = 16;
-  const char* env = getenv("G16_MSM_WINDOW");
-  if (env) {
+// Window size by a cost model: accumulation = n * nwin mixed adds (~10 modmul each); bucket reduction =
+// 2 XYZZ adds (~14 modmul each) per bucket, over nwin bucket sets -- or over ONE set when the points come
+// with precomputed 2^(c w) tables (`merged`).  A short top window (t = 254 - (nwin-1) c bits) would map all n
+// scalars onto 2^t buckets, so candidates need t >= min(c-2, 6).  2^20 points: c = 16 plain, c = 20 merged
+// (13 tables instead of 16 windows).
+static uint32_t pick_window_cost(size_t n, bool merged, const char* env_name, uint32_t cmax) {
+  if (const char* env = getenv(env_name)) {
     int v = atoi(env);
-    if (v >= 5 && v <= 20) c = v;
+    if (v >= 5 && v <= 22) return (uint32_t)v;
   }
-  return (uint32_t)c;
+  uint32_t best = 5;
+  double best_cost = 1e300;
+  for (uint32_t c = 5; c <= cmax; ++c) {
+    const uint32_t nwin = FR_BITS / c + 1;
+    if (((size_t)nwin * n) >> 31) continue;   // table index / entry count must fit 31 bits
+    const uint32_t t = FR_BITS - (nwin - 1) * c, tmin = c - 2 < 6 ? c - 2 : 6;
+    if (t < tmin && c > 5) continue;
+    const double sets = merged ? 1.0 : (double)nwin;
+    const double cost = 10.0 * (double)n * nwin + 28.0 * sets * (double)(1u << (c - 1));
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = c;
+    }
+  }
+  return best;
 }
+static uint32_t pick_window(size_t n) { return pick_window_cost(n ? n : 1, false, "G16_MSM_WINDOW", 16); }
 
 static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
   MsmParams P;
@@ -32,10 +46,17 @@ static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
   P.c = table_c ? table_c : pick_window(n);
   P.nwin = FR_BITS / P.c + 1;
   P.tables = table_c ? 1u : 0u;
-  P.nbuckets = P.nwin << (P.c - 1);
-  size_t avg = (n >> (P.c - 1)) + 1;
-  P.seg = (uint32_t)(((2 * avg + 31) / 32) * 32);
-  if (P.seg < 64) P.seg = 64;
+  P.nbuckets = P.tables ? (1u << (P.c - 1)) : (P.nwin << (P.c - 1));
+  // segment length L: one accumulate task handles <= L entries.  A task is a serial chain of L mixed adds
+  // (~23 us each with 4 waves per SIMD), so L also bounds the tail of the launch; ~1.25 x the mean bucket size
+  // keeps most buckets in one segment, the rest get 1-2 short extra segments that msm_reduce1 absorbs.
+  size_t avg = ((size_t)n * P.nwin) / P.nbuckets + 1;
+  P.seg = (uint32_t)(((avg + avg / 4 + 15) / 16) * 16);
+  if (P.seg < 32) P.seg = 32;
+  if (const char* env = getenv("G16_MSM_SEG")) {
+    int v = atoi(env);
+    if (v >= 8 && v <= 4096) P.seg = (uint32_t)v;
+  }
   P.scalars_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
   P.max_extra = (uint32_t)(((size_t)P.n * P.nwin) / P.seg + 1);
   return P;
@@ -60,13 +81,14 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
                o_blk = take(((nb + PERM_BLOCK - 1) / PERM_BLOCK) * PERM_BINS * 4);
   // partition sort (see msm.cuh): low bits <= 8, partitions = nwin << hi_bits
   const uint32_t lo_bits = P.c - 1 < 8 ? P.c - 1 : 8;
-  const uint32_t nparts = P.nwin << (P.c - 1 - lo_bits);
+  const uint32_t nparts = P.nbuckets >> lo_bits;
   const uint32_t ptiles = (P.n + PART_TILE - 1) / PART_TILE;
   const char* env_sort = getenv("G16_MSM_SORT");
-  const bool use_part = nparts <= PART_MAX && P.n < (1u << 23) && !(env_sort && env_sort[0] == 'a');
+  const bool use_part = nparts <= PART_MAX && !(env_sort && env_sort[0] == 'a');
   const size_t nth = (size_t)nparts * ptiles;
-  const size_t o_thist = take(use_part ? nth * 4 : 4), o_tmp = take(use_part ? (size_t)P.n * P.nwin * 4 : 4),
-               o_tiles2 = take(((nth + SCAN_TILE - 1) / SCAN_TILE) * 8 + 8);
+  const size_t o_thist = take(use_part ? nth * 4 : 4), o_tmp = take(use_part ? (size_t)P.n * P.nwin * 8 : 8),
+               o_tiles2 = take(((nth + SCAN_TILE - 1) / SCAN_TILE) * 8 + 8),
+               o_shist = take(use_part ? (size_t)nparts * BS_SPLIT * 256 * 4 : 4);
   int32_t rc = ensure(ctx, S.buf, o);
   if (rc) return rc;
   char* ws = (char*)S.buf.p;
@@ -83,8 +105,9 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   S.ghist = (uint32_t*)(ws + o_ghist);
   S.blk_base = (uint32_t*)(ws + o_blk);
   S.tile_hist = (uint32_t*)(ws + o_thist);
-  S.tmp = (uint32_t*)(ws + o_tmp);
+  S.tmp = (uint2*)(ws + o_tmp);
   S.tiles2 = (uint2*)(ws + o_tiles2);
+  S.slice_hist = (uint32_t*)(ws + o_shist);
   const auto* scalars = (const u256*)d_scalars;
   HIPCHK(ctx, hipMemsetAsync(ws + o_count, 0, o_offset - o_count, st));  // count + cursor are adjacent
   HIPCHK(ctx, hipMemsetAsync(S.info, 0, 64, st));
@@ -100,8 +123,10 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
     KLAUNCH_ON(ctx, st, "msm_scan", scan1_apply, nt2, SCAN_BLOCK, 0, S.tile_hist, (uint32_t)nth, S.tiles2);
     KLAUNCH_ON(ctx, st, "msm_part_scatter", part_pass<true>, ptiles, PART_BLOCK, 0, scalars, P, lo_bits, nparts,
                ptiles, S.tile_hist, S.tmp);
-    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_sort, nparts, 256, 0, S.tmp, S.tile_hist, ptiles, nparts, S.info + 8,
-               P, lo_bits, S.count, S.offset, S.entries);
+    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_hist, nparts * BS_SPLIT, 256, 0, S.tmp, S.tile_hist, ptiles, nparts,
+               S.info + 8, S.slice_hist);
+    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_place, nparts * BS_SPLIT, 256, 0, S.tmp, S.tile_hist, ptiles, nparts,
+               S.info + 8, S.slice_hist, P, lo_bits, S.count, S.offset, S.entries);
   } else {
     KLAUNCH_ON(ctx, st, "msm_count", msm_count, nblk, MSM_BLOCK, 0, scalars, P, S.count);
   }
@@ -136,7 +161,7 @@ static int32_t msm_reduce_device(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc
   const size_t nchunks = P.nbuckets / RED_CHUNK;
   const size_t o_partial = take(((size_t)P.nbuckets + P.max_extra) * sizeof(typename C::Acc)),
                o_chunkR = take(nchunks * sizeof(typename C::Acc)), o_chunkA = take(nchunks * sizeof(typename C::Acc)),
-               o_wsum = take((size_t)(P.nwin + 1) * sizeof(typename C::Acc));
+               o_wsum = take((size_t)(2 * 64 + 2) * sizeof(typename C::Acc));
   int32_t rc = ensure(ctx, acc, o);
   if (rc) return rc;
   char* ws = (char*)acc.p;
@@ -151,14 +176,27 @@ static int32_t msm_reduce_device(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc
              MSM_BLOCK, 0, points, S.entries, S.offset, S.xseg, S.info, S.perm, P, partial);
   KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, HEAVY_BLOCK,
              HEAVY_BLOCK * sizeof(typename C::Acc), S.heavy, S.info, S.offset, S.xoff, P, partial);
+  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy_small<C>, 256, MSM_BLOCK, 0, S.heavy, S.info,
+             S.offset, S.xoff, P, partial);
   KLAUNCH_ON(ctx, st, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>,
              (uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, partial, S.offset, P.nbuckets, chunkR,
              chunkA);
-  const uint32_t nsets = P.nwin;
+  // reduction sets: the windows themselves, or <= 64 slices of 2048 chunks of the merged bucket set
+  uint32_t nsets = P.nwin, log2ks = 0;
+  if (P.tables) {
+    uint32_t cps = nchunks < 2048 ? (uint32_t)nchunks : 2048u;
+    nsets = (uint32_t)(nchunks / cps);
+    for (uint32_t ks = cps * RED_CHUNK; ks > 1; ks >>= 1) ++log2ks;
+  }
+  auto* wtot = wsum + 65;
   KLAUNCH_ON(ctx, st, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", msm_reduce2<C>, nsets, RED2_BLOCK,
-             RED2_BLOCK * sizeof(typename C::Acc), chunkR, chunkA, (uint32_t)(nchunks / nsets), wsum);
-  KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets,
-             P.tables ? 0u : P.c, d_out_aff, d_out_acc);
+             RED2_BLOCK * sizeof(typename C::Acc), chunkR, chunkA, (uint32_t)(nchunks / nsets), wsum, wtot);
+  if (P.tables)
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, 1, 64, 64 * sizeof(typename C::Acc),
+               wsum, wtot, nsets, log2ks, d_out_aff, d_out_acc);
+  else
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets, P.c, d_out_aff,
+               d_out_acc);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
@@ -189,6 +227,8 @@ static int32_t sum_partials_device(g16_ctx* ctx, const void* d_parts, uint32_t c
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
+
+static uint32_t pick_table_window(size_t n) { return pick_window_cost(n ? n : 1, true, "G16_TABLE_WINDOW", 22); }
 
 template <class C>
 static int32_t precompute_device(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
