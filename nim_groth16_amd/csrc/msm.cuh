@@ -543,64 +543,58 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_reduce1(const typename C::Acc* 
   chunkR[j] = run;
   chunkA[j] = acc;
 }
-// stage 2: one workgroup per window over its M = K/RC chunks (index m = 0..M-1, bucket k = m*RC + 1 + i):
-//   S_w = sum_m A_m + RC * sum_m m * R_m ,   sum_m m R_m = sum_{m>=1} suffix(m)
-// done with a Hillis-Steele suffix scan + tree sums in LDS.  M may exceed the block: threads loop.
-constexpr int RED2_BLOCK = 256;
-template <class C>
-__global__ void __launch_bounds__(RED2_BLOCK) msm_reduce2(const typename C::Acc* __restrict__ chunkR,
-                                                          const typename C::Acc* __restrict__ chunkA,
-                                                          uint32_t chunks_per_window,
-                                                          typename C::Acc* __restrict__ window_sum,
-                                                          typename C::Acc* __restrict__ window_tot) {
+// stage 2: one workgroup per reduction set (a window, or a slice of the merged bucket set) over its M chunks
+// (chunk m holds buckets m*RC+1 .. (m+1)*RC of the set):
+//   S = sum_m A_m + RC * sum_m m * R_m ,      sum_m m R_m = sum_t [ wsum_t + lo_t * run_t ]
+// Thread t owns chunks [lo_t, lo_t + per): run_t = sum R, wsum_t = sum (m - lo_t) R_m, sumA_t = sum A_m by
+// running sums; sum_t lo_t run_t = per * sum_{t>=1} suffix(t) with suffix = inclusive suffix scan of run_t
+// (Hillis-Steele in LDS).  Each thread then forms  v_t = RC * (per * suffix_t[t>=1] + wsum_t) + sumA_t  with a
+// few doublings, and ONE LDS tree adds the v_t.  The whole kernel is a latency chain of ~40 group operations,
+// so the block is as wide as the register budget allows (BLOCK = 512 for G1, 256 for G2).
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) msm_reduce2(const typename C::Acc* __restrict__ chunkR,
+                                                     const typename C::Acc* __restrict__ chunkA,
+                                                     uint32_t chunks_per_window,
+                                                     typename C::Acc* __restrict__ window_sum,
+                                                     typename C::Acc* __restrict__ window_tot) {
   extern __shared__ __align__(16) unsigned char smem[];
   typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
   const uint32_t w = blockIdx.x, M = chunks_per_window;
   const typename C::Acc* R = chunkR + (size_t)w * M;
   const typename C::Acc* A = chunkA + (size_t)w * M;
-  // Each thread owns a contiguous slice of chunk indices [lo, hi): running sums inside the slice,
-  // then a block-level suffix scan of the slice totals.
-  const uint32_t per = (M + RED2_BLOCK - 1) / RED2_BLOCK;
+  const uint32_t per = (M + BLOCK - 1) / BLOCK;
   const uint32_t lo = threadIdx.x * per, hi = (lo + per < M) ? lo + per : M;
   typename C::Acc sumA = C::acc_inf(), run = C::acc_inf(), wsum = C::acc_inf();
-  // local: run = sum_{m in slice} R_m ; wsum = sum_{m in slice} (m - lo) R_m   (descending running sum)
   if (lo < M) {
     for (uint32_t m = hi; m-- > lo;) {
-      C::add(wsum, run);      // wsum += sum_{m' > m} R_m'   -> each R_m' counted (m' - m) times; ends at m = lo
+      C::add(wsum, run);   // each R_m' ends up counted (m' - lo) times
       C::add(run, R[m]);
       C::add(sumA, A[m]);
     }
   }
-  // block suffix scan (exclusive) of slice totals `run`:  above_t = sum_{t' > t} run_t'
+  // inclusive suffix scan of the slice totals
   sh[threadIdx.x] = run;
   __syncthreads();
   typename C::Acc incl = run;
 #pragma unroll 1
-  for (int d = 1; d < RED2_BLOCK; d <<= 1) {
+  for (int d = 1; d < BLOCK; d <<= 1) {
     typename C::Acc other = C::acc_inf();
-    bool has = (int)threadIdx.x + d < RED2_BLOCK;
+    const bool has = (int)threadIdx.x + d < BLOCK;
     if (has) other = sh[threadIdx.x + d];
     __syncthreads();
     if (has) C::add(incl, other);
     sh[threadIdx.x] = incl;
     __syncthreads();
   }
-  // sum_m m R_m = sum_t [ wsum_t + lo_t * run_t ]  with  lo_t * run_t summed as: each slice total is
-  // counted once for every chunk index below its slice start.  Using suffix sums:
-  //   sum_t lo_t run_t = per * sum_{t>=1} suffix_incl(t)        (lo_t = t * per)
-  typename C::Acc suf = (threadIdx.x >= 1 && lo < M) ? incl : C::acc_inf();
   if (threadIdx.x == 0) window_tot[w] = incl;   // sum of every bucket of this set
+  // v_t = RC * (per * suffix_t + wsum_t) + sumA_t
+  typename C::Acc v = (threadIdx.x >= 1 && lo < M) ? C::mul_small(incl, per) : C::acc_inf();
+  C::add(v, wsum);
+  v = C::mul_small(v, RED_CHUNK);
+  C::add(v, sumA);
   __syncthreads();
-  typename C::Acc sufsum = block_sum<C, RED2_BLOCK>(suf, sh);
-  typename C::Acc wtot = block_sum<C, RED2_BLOCK>(wsum, sh);
-  typename C::Acc atot = block_sum<C, RED2_BLOCK>(sumA, sh);
-  if (threadIdx.x == 0) {
-    typename C::Acc t = C::mul_small(sufsum, per);  // per * sum suffix
-    C::add(t, wtot);                                // = sum_m m R_m
-    t = C::mul_small(t, RED_CHUNK);                 // * RC
-    C::add(t, atot);
-    window_sum[w] = t;
-  }
+  typename C::Acc tot = block_sum<C, BLOCK>(v, sh);
+  if (threadIdx.x == 0) window_sum[w] = tot;
 }
 
 // ---- K7: fold windows + canonical affine ------------------------------------------------------------

@@ -189,8 +189,9 @@ static int32_t msm_reduce_device(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc
     for (uint32_t ks = cps * RED_CHUNK; ks > 1; ks >>= 1) ++log2ks;
   }
   auto* wtot = wsum + 65;
-  KLAUNCH_ON(ctx, st, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", msm_reduce2<C>, nsets, RED2_BLOCK,
-             RED2_BLOCK * sizeof(typename C::Acc), chunkR, chunkA, (uint32_t)(nchunks / nsets), wsum, wtot);
+  constexpr int R2B = sizeof(typename C::Aff) == 64 ? 512 : 256;   // as wide as the register budget allows
+  KLAUNCH_ON(ctx, st, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", (msm_reduce2<C, R2B>), nsets, R2B,
+             R2B * sizeof(typename C::Acc), chunkR, chunkA, (uint32_t)(nchunks / nsets), wsum, wtot);
   if (P.tables)
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, 1, 64, 64 * sizeof(typename C::Acc),
                wsum, wtot, nsets, log2ks, d_out_aff, d_out_acc);

@@ -11,6 +11,7 @@
 
 #include "g16_internal.hpp"
 #include "ec.cuh"
+#include "host_ff64.hpp"
 
 using namespace g16;
 
@@ -57,26 +58,45 @@ static __global__ void __launch_bounds__(256) abc_spmv(const uint32_t* __restric
 }
 
 // ---- host-side O(1) curve helpers (the reference does these on the host too: curves.nim:136-214) ------
-template <class C>
-static typename C::Aff host_mul(const u256& k_std, const typename C::Aff& p) {
-  typename C::Acc acc = C::acc_inf();
-  const typename C::Acc base = C::from_affine(p);
-  bool started = false;
+// 64-bit-limb host field (host_ff64.hpp) under the same curve templates; 4-bit fixed windows.
+using HG1 = Curve<HFp>;
+using HG2 = Curve<HFp2>;
+template <class HC, class DevAff>
+static DevAff host_mul(const u256& k_std, const DevAff& p_dev) {
+  static_assert(sizeof(DevAff) == sizeof(typename HC::Aff), "layout");
+  typename HC::Aff p;
+  memcpy(&p, &p_dev, sizeof p);
+  typename HC::Acc tab[16];
+  tab[0] = HC::acc_inf();
+  tab[1] = HC::from_affine(p);
+  for (int i = 2; i < 16; ++i) {
+    tab[i] = tab[i - 1];
+    HC::madd(tab[i], p);
+  }
+  typename HC::Acc acc = HC::acc_inf();
   for (int i = 7; i >= 0; --i)
-    for (int b = 31; b >= 0; --b) {
-      if (started) acc = C::dbl(acc);
-      if ((k_std.v[i] >> b) & 1) {
-        C::add(acc, base);
-        started = true;
-      }
+    for (int nib = 7; nib >= 0; --nib) {
+      if (!HC::is_inf(acc))
+        for (int d = 0; d < 4; ++d) acc = HC::dbl(acc);
+      uint32_t w = (k_std.v[i] >> (4 * nib)) & 15u;
+      if (w) HC::add(acc, tab[w]);
     }
-  return C::to_affine(acc);
+  typename HC::Aff r = HC::to_affine(acc);
+  DevAff out;
+  memcpy(&out, &r, sizeof out);
+  return out;
 }
-template <class C>
-static typename C::Aff host_add(const typename C::Aff& a, const typename C::Aff& b) {
-  typename C::Acc acc = C::from_affine(a);
-  C::madd(acc, b);
-  return C::to_affine(acc);
+template <class HC, class DevAff>
+static DevAff host_add(const DevAff& a_dev, const DevAff& b_dev) {
+  typename HC::Aff a, b;
+  memcpy(&a, &a_dev, sizeof a);
+  memcpy(&b, &b_dev, sizeof b);
+  typename HC::Acc acc = HC::from_affine(a);
+  HC::madd(acc, b);
+  typename HC::Aff r = HC::to_affine(acc);
+  DevAff out;
+  memcpy(&out, &r, sizeof out);
+  return out;
 }
 
 extern "C" void g16_pkey_destroy(g16_pkey* k) {
@@ -340,21 +360,21 @@ extern "C" int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* k, const void
   if (mask_s) memcpy(&s, mask_s, 32);
   const u256 r_std = Fr::from_mont(r), s_std = Fr::from_mont(s);
   const u256 mrs_std = Fr::from_mont(Fr::neg(Fr::mul(r, s)));
-  const g1_aff r_delta1 = host_mul<G1>(r_std, k->delta1);
-  const g1_aff s_delta1 = host_mul<G1>(s_std, k->delta1);
-  const g2_aff s_delta2 = host_mul<G2>(s_std, k->delta2);
-  const g1_aff mrs_delta1 = host_mul<G1>(mrs_std, k->delta1);
+  const g1_aff r_delta1 = host_mul<HG1>(r_std, k->delta1);
+  const g1_aff s_delta1 = host_mul<HG1>(s_std, k->delta1);
+  const g2_aff s_delta2 = host_mul<HG2>(s_std, k->delta2);
+  const g1_aff mrs_delta1 = host_mul<HG1>(mrs_std, k->delta1);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 
   // prover.nim:279-302
-  g1_aff pi_a = host_add<G1>(host_add<G1>(k->alpha1, r_delta1), res.a);
-  g1_aff rho = host_add<G1>(host_add<G1>(k->beta1, s_delta1), res.b1);
-  g2_aff pi_b = host_add<G2>(host_add<G2>(k->beta2, s_delta2), res.b2);
-  g1_aff pi_c = host_mul<G1>(s_std, pi_a);
-  pi_c = host_add<G1>(pi_c, host_mul<G1>(r_std, rho));
-  pi_c = host_add<G1>(pi_c, mrs_delta1);
-  pi_c = host_add<G1>(pi_c, res.h);
-  pi_c = host_add<G1>(pi_c, res.c);
+  g1_aff pi_a = host_add<HG1>(host_add<HG1>(k->alpha1, r_delta1), res.a);
+  g1_aff rho = host_add<HG1>(host_add<HG1>(k->beta1, s_delta1), res.b1);
+  g2_aff pi_b = host_add<HG2>(host_add<HG2>(k->beta2, s_delta2), res.b2);
+  g1_aff pi_c = host_mul<HG1>(s_std, pi_a);
+  pi_c = host_add<HG1>(pi_c, host_mul<HG1>(r_std, rho));
+  pi_c = host_add<HG1>(pi_c, mrs_delta1);
+  pi_c = host_add<HG1>(pi_c, res.h);
+  pi_c = host_add<HG1>(pi_c, res.c);
   memcpy(out->pi_a, &pi_a, 64);
   memcpy(out->pi_b, &pi_b, 128);
   memcpy(out->pi_c, &pi_c, 64);
