@@ -35,7 +35,10 @@ def main():
     ap.add_argument("--log2n", type=int, default=20, help="domain size 2^log2n (constraints m = 2^log2n - 2)")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend; gloo only for rehearsing the multi-process path on a one-GPU box "
+                         "(all ranks then share device 0)")
+    ap.add_argument("--inflight", type=int, default=3,
                     help="replica mode: proofs in flight per GPU (each has its own context, streams and key copy); "
                          "the latency-bound tail of one proof overlaps the accumulation of the next")
     args = ap.parse_args()
@@ -48,12 +51,18 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if args.backend == "gloo":
+        local = 0                      # rehearsal: every rank computes on device 0
     torch.cuda.set_device(local)
     dist = None
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from nim_groth16_amd import Context, Mask, Witness, loadProvingKey
     from nim_groth16_amd import bn128 as F
@@ -93,13 +102,16 @@ def main():
     if shard:
         from nim_groth16_amd._lib import PARTIALS_BYTES
         mine = torch.empty(PARTIALS_BYTES, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(world * PARTIALS_BYTES, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(world * PARTIALS_BYTES, dtype=torch.uint8, device=coll_dev)
 
-        def step():
+        def step(lane=0):
             pkey.prove_partials(d_w.data_ptr(), mont=True, device=True, out=mine.data_ptr())
-            dist.all_gather_into_tensor(gathered, mine)
-            torch.cuda.current_stream().synchronize()
-            return pkey.prove_combine(gathered.data_ptr(), world, rb, sb, device=True)
+            if coll_dev == "cuda":      # one RCCL all-gather of 768-byte records per proof
+                dist.all_gather_into_tensor(gathered, mine)
+                torch.cuda.current_stream().synchronize()
+                return pkey.prove_combine(gathered.data_ptr(), world, rb, sb, device=True)
+            dist.all_gather_into_tensor(gathered, mine.cpu())
+            return pkey.prove_combine(gathered.numpy().tobytes(), world, rb, sb)
     else:
         def step(lane=0):
             return lanes[lane][1].prove(d_w.data_ptr(), mont=True, r=rb, s=sb, device=True)
@@ -143,7 +155,7 @@ def main():
         step()
     lat_ms = (time.perf_counter() - t1) / 3 * 1e3
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     proofs = args.steps * (1 if shard or world == 1 else world)
@@ -151,14 +163,15 @@ def main():
 
     # ---- per-kernel HIP-event timing of the same step (roofline of the dominant kernel) ---------------------
     roof, extra = None, {}
-    if rank == 0:
-        ctx.profile(True)
+    reps = 3
+    if rank == 0 or shard:            # in shard mode a step contains a collective: every rank must take part
+        ctx.profile(rank == 0)
         ctx.profile_reset()
-        reps = 3
         for _ in range(reps):
             step()
         rep = ctx.profile_report()
         ctx.profile(False)
+    if rank == 0:
         kern = {k: v["total_ms"] / v["calls"] for k, v in rep.items()}
         calls = {k: v["calls"] // reps for k, v in rep.items()}
         dom = max(rep, key=lambda k: rep[k]["total_ms"])
