@@ -182,8 +182,16 @@ def main():
         if dom in ("msm_count", "msm_scatter"):
             alg = 32 * nsh
         achieved = alg / (kern[dom] * 1e-3) / 1e9
+        # measured HBM bytes per launch of that kernel (rocprofv3 PMC passes, profiles/r01_pmc_hbm_traffic_2p20.json)
+        traffic = None
+        try:
+            if args.log2n == 20 and not shard:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_2p20.json")))
+                traffic = pm["kernels"][dom]["hbm_bytes_per_launch_raw"]
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                 "avg_launch_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": alg,
                 "note": "MSM is integer-ALU-bound (254-bit Montgomery madds), not HBM-bound: see DESIGN.md"}
         extra["kernel_ms_per_proof"] = {k: round(kern[k] * calls[k], 4) for k in sorted(kern)}
