@@ -11,6 +11,18 @@ frInvMontR = pow(_MONT, -1, primeR)                                            #
 gen28 = 0x2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0     # domain.nim:26
 
 
+fpMontR = _MONT % primeP                                                       # io.nim:87
+fpInvMontR = pow(_MONT, -1, primeP)                                            # io.nim:88
+
+
+def fpFromMontBytes(b: bytes) -> int:
+    return int.from_bytes(b, "little") * fpInvMontR % primeP
+
+
+def fpToMontBytes(x: int) -> bytes:
+    return (x % primeP * fpMontR % primeP).to_bytes(32, "little")
+
+
 def frToMontBytes(x: int) -> bytes:
     """in-memory Fr (constantine limbs): Montgomery, little-endian"""
     return (x % primeR * frMontR % primeR).to_bytes(32, "little")

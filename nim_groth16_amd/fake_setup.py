@@ -29,6 +29,7 @@ class R1CS:                          # files/r1cs.nim:62-80; constraint = (A, B,
     nPubIn: int
     nPrivIn: int
     constraints: list
+    wireToLabel: list = None
 
 
 def r1csToCoeffs(r1cs: R1CS):

@@ -17,7 +17,8 @@ from .zkey_types import ZKey, packCoeffs
 class Witness:                       # files/witness.nim:27-32
     curve: str
     nvars: int
-    values: bytes                    # nvars Fr, Montgomery (the Nim seq[Fr] layout)
+    values: bytes                    # nvars Fr: Montgomery (the Nim seq[Fr] layout), or ...
+    std: bool = False                # ... standard form (raw .wtns bytes, files/witness.nim:14) when True
 
 
 @dataclass
@@ -79,8 +80,10 @@ def generateProofWithMask(nthreads: int, printTimings: bool, zkey: ZKey, wtns: W
     pkey = pkey or _pkey_for(zkey, ctx)
     r = F.frToMontBytes(mask.r) if mask.r % F.primeR else None
     s = F.frToMontBytes(mask.s) if mask.s % F.primeR else None
-    pi_a, pi_b, pi_c = pkey.prove(wtns.values, mont=True, r=r, s=s)
+    pi_a, pi_b, pi_c = pkey.prove(wtns.values, mont=not wtns.std, r=r, s=s)
     pubIO = wtns.values[: 32 * (zkey.header.npubs + 1)]
+    if wtns.std:                     # Proof.publicIO is seq[Fr]: Montgomery in memory
+        pubIO = F.frSeqToMontBytes(int.from_bytes(pubIO[i:i + 32], "little") for i in range(0, len(pubIO), 32))
     return Proof(pubIO, pi_a, pi_b, pi_c)
 
 

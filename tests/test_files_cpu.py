@@ -1,0 +1,92 @@
+"""Host-side file formats (mirrors of groth16/files/*.nim): writer -> parser round trips on the reference's toy
+circuit, byte-level checks of the layout facts the GPU path relies on, JSON export shape.  No GPU needed: the
+key comes from the oracle's fake setup."""
+import json
+import struct
+
+import pytest
+
+from oracle import bn254_ref as o
+from tests import inputs as I
+
+
+def _toy_zkey():
+    from nim_groth16_amd.zkey_types import GrothHeader, ProverPoints, SpecPoints, ZKey
+    rng = o.SplitMix64(123)
+    oz = o.fake_circuit_setup(o.toy_r1cs(), o.ToxicWaste(*[rng.fr() for _ in range(5)]), o.SNARKJS)
+    g1 = lambda ps: b"".join(o.g1_to_bytes(p) for p in ps)      # noqa: E731
+    g2 = lambda ps: b"".join(o.g2_to_bytes(p) for p in ps)      # noqa: E731
+    zk = ZKey(GrothHeader("bn128", 1, oz.nvars, oz.npubs, oz.domainSize, oz.logDomainSize),
+              SpecPoints(o.g1_to_bytes(oz.alpha1), o.g1_to_bytes(oz.beta1), o.g2_to_bytes(oz.beta2),
+                         o.g2_to_bytes(oz.gamma2), o.g1_to_bytes(oz.delta1), o.g2_to_bytes(oz.delta2)),
+              g1(oz.pointsIC), ProverPoints(g1(oz.pointsA1), g1(oz.pointsB1), g2(oz.pointsB2), g1(oz.pointsC1),
+                                            g1(oz.pointsH1)),
+              [(m, r, c, o.fr_to_mont_bytes(v)) for (m, r, c, v) in oz.coeffs])
+    return zk, oz
+
+
+def test_zkey_roundtrip_and_layout(tmp_path):
+    from nim_groth16_amd.files import parseZKey, writeZKey
+    zk, oz = _toy_zkey()
+    path = str(tmp_path / "toy.zkey")
+    writeZKey(path, zk)
+    back = parseZKey(path)
+    assert back == zk
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"zkey" and struct.unpack_from("<II", raw, 4) == (1, 9)      # container.nim:6-20
+    # section 4 stores c * R^2 (double Montgomery, zkey.nim:57): the last dummy coefficient is 1 -> R^2 mod r
+    assert (o.MONT * o.MONT % o.R).to_bytes(32, "little") in raw
+    # point sections are the in-memory Montgomery layout: gen-derived point bytes appear verbatim
+    assert zk.pPoints.pointsA1 in raw and zk.pPoints.pointsB2 in raw
+
+
+def test_zkey_parser_rejects_bad_files(tmp_path):
+    from nim_groth16_amd.files import parseZKey, writeZKey
+    zk, _ = _toy_zkey()
+    path = str(tmp_path / "bad.zkey")
+    writeZKey(path, zk)
+    raw = bytearray(open(path, "rb").read())
+    raw[0:4] = b"wtns"
+    open(path, "wb").write(raw)
+    with pytest.raises(AssertionError):
+        parseZKey(path)                                                  # container.nim:85
+
+
+def test_witness_roundtrip(tmp_path):
+    from nim_groth16_amd.files import parseWitness, writeWitness
+    path = str(tmp_path / "toy.wtns")
+    writeWitness(path, o.TOY_WITNESS)
+    w = parseWitness(path)
+    assert w.curve == "bn128" and w.nvars == 8 and w.std
+    assert w.values == I.fr_std_bytes(o.TOY_WITNESS)                     # standard form, witness.nim:14
+    assert open(path, "rb").read()[:4] == b"wtns"
+
+
+def test_r1cs_roundtrip(tmp_path):
+    from nim_groth16_amd.fake_setup import R1CS
+    from nim_groth16_amd.files import parseR1CS, writeR1CS
+    toy = o.toy_r1cs()
+    r1 = R1CS(8, 1, 1, 3, toy.constraints)
+    path = str(tmp_path / "toy.r1cs")
+    writeR1CS(path, r1)
+    back = parseR1CS(path)
+    assert (back.nWires, back.nPubOut, back.nPubIn, back.nPrivIn) == (8, 1, 1, 3)
+    assert back.constraints == [tuple([(i, v % o.R) for (i, v) in lc] for lc in c) for c in toy.constraints]
+    assert back.wireToLabel == list(range(8))
+
+
+def test_export_json(tmp_path):
+    from nim_groth16_amd.files import exportProof, exportPublicIO
+    from nim_groth16_amd.prover import Proof
+    _, oz = _toy_zkey()
+    ref = o.generate_proof_with_mask(oz, o.TOY_WITNESS, 11, 22)
+    prf = Proof(I.fr_mont_bytes(ref.publicIO), o.g1_to_bytes(ref.pi_a), o.g2_to_bytes(ref.pi_b), o.g1_to_bytes(ref.pi_c))
+    pj, ij = str(tmp_path / "proof.json"), str(tmp_path / "public.json")
+    exportProof(pj, prf)
+    exportPublicIO(ij, prf)
+    d = json.load(open(pj))
+    assert d["protocol"] == "groth16" and d["curve"] == "bn128"
+    assert [int(x) for x in d["pi_a"]] == [ref.pi_a[0], ref.pi_a[1], 1]                     # export_json.nim:55-59
+    assert [[int(x) for x in row] for row in d["pi_b"]] == [list(ref.pi_b[0]), list(ref.pi_b[1]), [1, 0]]
+    assert [int(x) for x in d["pi_c"]] == [ref.pi_c[0], ref.pi_c[1], 1]
+    assert [int(x) for x in json.load(open(ij))] == [2023, 1022]                            # constant 1 skipped

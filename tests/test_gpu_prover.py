@@ -148,3 +148,35 @@ def test_sharded_proof_single_gpu(ctx, world):
         keys[0].prove(wb)                      # a sharded key cannot prove alone
     for k in keys + [full]:
         k.destroy()
+
+
+def test_files_to_proof_json_end_to_end(ctx, tmp_path):
+    """snarkjs-style pipeline (groth16/example/prove.sh:52-59 without circom/snarkjs): .zkey + .wtns files ->
+    parse -> GPU prove (raw standard-form witness bytes) -> proof.json / public.json -> verified by the oracle"""
+    import json
+    from nim_groth16_amd import Mask, generateProofWithMask
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.files import exportProof, exportPublicIO, parseWitness, parseZKey, writeWitness, writeZKey
+    a, b, g, d, t = _toxic(25)
+    toy = o.toy_r1cs()
+    zk0 = fakeCircuitSetup(R1CS(8, 1, 1, 3, toy.constraints), ToxicWaste(a, b, g, d, t), 1, ctx)
+    zpath, wpath = str(tmp_path / "c.zkey"), str(tmp_path / "c.wtns")
+    writeZKey(zpath, zk0)
+    writeWitness(wpath, o.TOY_WITNESS)
+    zk, wt = parseZKey(zpath), parseWitness(wpath)
+    assert zk == zk0 and wt.std
+    rng = o.SplitMix64(26)
+    r, s = rng.fr(), rng.fr()
+    pr = generateProofWithMask(0, False, zk, wt, Mask(r, s), ctx)
+    pj, ij = str(tmp_path / "proof.json"), str(tmp_path / "public.json")
+    exportProof(pj, pr)
+    exportPublicIO(ij, pr)
+    dj = json.load(open(pj))
+    oz = o.fake_circuit_setup(toy, o.ToxicWaste(a, b, g, d, t), o.SNARKJS)
+    ref = o.generate_proof_with_mask(oz, o.TOY_WITNESS, r, s)
+    got = o.Proof([1] + [int(x) for x in json.load(open(ij))],
+                  (int(dj["pi_a"][0]), int(dj["pi_a"][1])),
+                  ((int(dj["pi_b"][0][0]), int(dj["pi_b"][0][1])), (int(dj["pi_b"][1][0]), int(dj["pi_b"][1][1]))),
+                  (int(dj["pi_c"][0]), int(dj["pi_c"][1])))
+    assert (got.pi_a, got.pi_b, got.pi_c, got.publicIO) == (ref.pi_a, ref.pi_b, ref.pi_c, ref.publicIO)
+    assert o.verify_proof(oz, got)
