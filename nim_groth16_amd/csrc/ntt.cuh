@@ -84,6 +84,9 @@ static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restr
   const uint32_t tile = R << log2b;
   const uint32_t tid = threadIdx.x;
 
+  // inner-stage twiddles w_R^t (t < R/2) once per workgroup into LDS, behind the tile
+  u256* twl = lds + tile;
+  for (uint32_t t = tid; t < (R >> 1); t += NTT_BLOCK) twl[t] = ntt_tw(tw, t << (log2n - rho), log2n, inverse);
   // load: element (r, b) <- x[base0 + b + nR * r]   (LDS index r*B + b)
   for (uint32_t e = tid; e < tile; e += NTT_BLOCK) {
     uint32_t b = e & (B - 1), r = e >> log2b;
@@ -91,7 +94,7 @@ static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restr
   }
   __syncthreads();
 
-  // rho DIF stages: half distance h = R/2 ... 1 ; twiddle w_(2h)^p = w_n^(p * n/(2h))
+  // rho DIF stages: half distance h = R/2 ... 1 ; twiddle w_(2h)^p = w_R^(p * R/(2h))
   for (uint32_t lh = rho; lh-- > 0;) {
     const uint32_t h = 1u << lh;
     for (uint32_t bf = tid; bf < (tile >> 1); bf += NTT_BLOCK) {
@@ -101,7 +104,7 @@ static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restr
       uint32_t ia = (i << log2b) | b, ib = ((i + h) << log2b) | b;
       u256 a = lds[ia], c = lds[ib];
       u256 sum = Fr::add(a, c), dif = Fr::sub(a, c);
-      if (p) dif = Fr::mul(dif, ntt_tw(tw, p << (log2n - lh - 1), log2n, inverse));  // p == 0: twiddle 1
+      if (p) dif = Fr::mul(dif, twl[p << (rho - lh - 1)]);  // p == 0: twiddle 1
       lds[ia] = sum;
       lds[ib] = dif;
     }

@@ -37,13 +37,13 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
   uint32_t log2s = 0;
   for (uint32_t p = 0; p < npass; ++p) {
     uint32_t rho = log2n / npass + (p < log2n % npass ? 1u : 0u);
-    uint32_t log2b = 11 - rho;
+    uint32_t log2b = 10 - rho;   // 1024-element (32 KB) tiles: 4 workgroups per CU
     if (log2b > log2n - rho) log2b = log2n - rho;
     const bool last = p + 1 == npass;
     u256* dst = last ? out : ((p & 1) ? tmpB : tmpA);
     const size_t dst_stride = last ? out_stride : n;
     const dim3 grid(1u << (log2n - rho - log2b), batch);
-    const size_t shmem = (size_t(32) << (rho + log2b));
+    const size_t shmem = (size_t(32) << (rho + log2b)) + (size_t(16) << rho);   // tile + R/2 twiddles
     KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass, grid, NTT_BLOCK, shmem, src, dst,
             (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse, last ? 1 : 0, src_stride, dst_stride,
             last ? scale : (const u256*)nullptr);

@@ -8,7 +8,10 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nim_groth16_amd import Context, generateProof, generateProofWithTrivialMask, loadProvingKey  # noqa: E402
+import secrets  # noqa: E402
+
+from nim_groth16_amd import Context, Mask, generateProofWithMask, loadProvingKey  # noqa: E402
+from nim_groth16_amd import bn128 as F  # noqa: E402
 from nim_groth16_amd.files import exportProof, exportPublicIO, parseWitness, parseZKey  # noqa: E402
 
 
@@ -26,10 +29,10 @@ def main():
     t0 = time.time()
     zkey, wtns = parseZKey(args.zkey), parseWitness(args.wtns)
     t1 = time.time()
-    loadProvingKey(zkey, ctx)
+    pkey = loadProvingKey(zkey, ctx)
     t2 = time.time()
-    prove = generateProofWithTrivialMask if args.nomask else generateProof
-    proof = prove(0, args.time, zkey, wtns, ctx)
+    mask = Mask(0, 0) if args.nomask else Mask(secrets.randbelow(F.primeR), secrets.randbelow(F.primeR))
+    proof = generateProofWithMask(0, args.time, zkey, wtns, mask, ctx, pkey=pkey)
     t3 = time.time()
     exportProof(args.output, proof)
     exportPublicIO(args.io, proof)
