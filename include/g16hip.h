@@ -86,13 +86,17 @@ int32_t g16_g2_sum_partials(g16_ctx* ctx, const void* xyzz, size_t count, void* 
  * The five ProverPoints arrays (pointsA1/B1/B2/C1/H1, groth16/zkey_types.nim:36-41) are constant per
  * circuit and are loaded once (files/zkey.nim:201-224).  Registering a set copies it to HBM and
  * precomputes the window tables 2^(c w) * P_i, so that no MSM against it contains a doubling chain.
- * HBM cost: (254/c + 1) x the point set (c = 16 for n >= 2^20: 1 GiB per 2^20 G1 points). */
+ * Because the factor lives in the table, all windows share one bucket set and the window size c is chosen
+ * by a cost model (c = 20 for 2^20 points: 13 tables, 832 MiB per 2^20 G1 points, 1.6 GiB for G2). */
 int32_t g16_points_register_g1(g16_ctx* ctx, const void* points, size_t n, g16_points** out);
 int32_t g16_points_register_g2(g16_ctx* ctx, const void* points, size_t n, g16_points** out);
 int32_t g16_points_register_g1_dev(g16_ctx* ctx, const void* d_points, size_t n, g16_points** out);
 int32_t g16_points_register_g2_dev(g16_ctx* ctx, const void* d_points, size_t n, g16_points** out);
 void g16_points_release(g16_points* pts);
 size_t g16_points_count(const g16_points* pts);
+/* window size c and number of tables (= windows) chosen for this set; an MSM against it performs
+ * count * ntables bucket additions + 2 * 2^(c-1) reduction additions */
+int32_t g16_points_info(const g16_points* pts, uint32_t* window_bits, uint32_t* ntables);
 /* sum_i scalars[i] * P_i over the whole registered set (scalars: g16_points_count elements);
  * flags = G16_SCALARS_MONT/STD | G16_SCALARS_DEVICE | G16_OUT_PARTIAL.  This is the call a prover makes
  * per proof for msmMultiThreadedG1/G2 (groth16/prover.nim:282,288,294,301,302). */

@@ -18,7 +18,7 @@ SYMBOLS = [
     "g16_selftest", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
     "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
-    "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_msm_points",
+    "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_info", "g16_msm_points",
     "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
     "g16_pkey_destroy", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
@@ -87,6 +87,7 @@ def load_library():
     lib.g16_points_release.restype = None
     lib.g16_points_count.argtypes = [vp]
     lib.g16_points_count.restype = sz
+    lib.g16_points_info.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     lib.g16_msm_points.argtypes = [vp, vp, vp, u32, vp]
     lib.g16_fixed_base_g1.argtypes = [vp, vp, u32, sz, vp]
     lib.g16_fixed_base_g2.argtypes = [vp, vp, u32, sz, vp]
@@ -310,6 +311,12 @@ class PointSet:
     def __init__(self, ctx: Context, handle, group: int, n: int):
         self.ctx, self._h, self.group, self.n = ctx, handle, group, n
         ctx._children.add(self)
+
+    def info(self):
+        """(window bits c, number of tables)"""
+        c, w = ctypes.c_uint32(), ctypes.c_uint32()
+        self.ctx._check(self.ctx._lib.g16_points_info(self._h, ctypes.byref(c), ctypes.byref(w)))
+        return c.value, w.value
 
     def _free(self):
         if self._h and self.ctx._h:

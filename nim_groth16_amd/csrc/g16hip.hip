@@ -249,6 +249,12 @@ extern "C" void g16_points_release(g16_points* h) {
   delete h;
 }
 extern "C" size_t g16_points_count(const g16_points* h) { return h ? h->n : 0; }
+extern "C" int32_t g16_points_info(const g16_points* h, uint32_t* window_bits, uint32_t* ntables) {
+  if (!h) return G16_EINVAL;
+  if (window_bits) *window_bits = h->c;
+  if (ntables) *ntables = h->nwin;
+  return G16_OK;
+}
 
 // out[i] = scalars[i] * generator  (`y ** gen1` / `y ** gen2`, fake_setup.nim:258-261); host pointers
 static int32_t fixed_base(g16_ctx* ctx, int group, const void* scalars, uint32_t flags, size_t n, void* out) {
