@@ -58,20 +58,6 @@ FF_HD void mac(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
   hi += (uint32_t)(t >> 64);
 #endif
 }
-// same with a wave-uniform multiplier (a modulus limb) held in an SGPR
-FF_HD void mac_k(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(lo), "+v"(hi)
-      : "v"(a), "s"(k)
-      : "vcc");
-#else
-  mac(lo, hi, a, k);
-#endif
-}
-// (lo:64) += a*b, caller knows the sum cannot overflow 64 bits
-FF_HD void mac_nc(uint64_t& lo, uint32_t a, uint32_t b) { lo += (uint64_t)a * b; }
-
 // column shift: (lo,hi) >>= 32
 FF_HD void acc_shift(uint64_t& lo, uint32_t& hi) {
   lo = (lo >> 32) | ((uint64_t)hi << 32);

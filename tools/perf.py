@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--g2", type=int, default=1)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--dist", choices=["uniform", "circom"], default="uniform",
+                    help="circom: 40 %% zero, 30 %% one, 10 %% < 2^16, 20 %% uniform (SURVEY 8d config 2-ii)")
     args = ap.parse_args()
     n = 1 << args.log2n
     orc = load_oracle()
@@ -36,6 +38,18 @@ def main():
     p1 = orc.fixed_base(1, kb)
     print(f"gen G1 points {time.time()-t:.1f}s", flush=True)
     sb = rand_fr_mont_bytes(n, 2)
+    if args.dist == "circom":
+        from oracle import bn254_ref as o
+        rng = np.random.default_rng(3)
+        u = rng.integers(0, 100, size=n)
+        arr = np.frombuffer(bytearray(sb), dtype=np.uint64).reshape(n, 4).copy()
+        one = np.frombuffer(o.fr_to_mont_bytes(1), dtype=np.uint64)
+        arr[u < 40] = 0
+        arr[(u >= 40) & (u < 70)] = one
+        small = np.where((u >= 70) & (u < 80))[0]
+        sm = [o.fr_to_mont_bytes(int(v)) for v in rng.integers(0, 1 << 16, size=len(small))]
+        arr[small] = np.frombuffer(b"".join(sm), dtype=np.uint64).reshape(-1, 4)
+        sb = arr.tobytes()
     d_s = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
     d_p1 = torch.frombuffer(bytearray(p1), dtype=torch.uint8).cuda()
     torch.cuda.synchronize()
