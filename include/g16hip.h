@@ -102,6 +102,13 @@ int32_t g16_points_info(const g16_points* pts, uint32_t* window_bits, uint32_t* 
  * per proof for msmMultiThreadedG1/G2 (groth16/prover.nim:282,288,294,301,302). */
 int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const void* scalars, uint32_t flags, void* out);
 
+/* ---- curve membership of a point array: replaces the per-point asserts of mkG1 / mkG2 that the reference runs
+ * while loading a .zkey (groth16/bn128/curves.nim:95-107 via io.nim:240-250).  *first_bad = index of the first
+ * point that is neither (0,0) nor on y^2 = x^3 + b, or (size_t)-1 when all are fine.  Like the reference this is
+ * NOT a subgroup check.  Host pointers. */
+int32_t g16_points_check_g1(g16_ctx* ctx, const void* points, size_t n, size_t* first_bad);
+int32_t g16_points_check_g2(g16_ctx* ctx, const void* points, size_t n, size_t* first_bad);
+
 /* ---- fixed-base multiples of the generators: out[i] = scalars[i] * gen1 (resp. gen2) --------------------
  * replaces the `y ** gen1` / `y ** gen2` comprehensions of the fake trusted setup
  * (groth16/fake_setup.nim:258-261, 273-277, 290-302; generators: curves.nim:112-124).  Used to build

@@ -19,7 +19,7 @@ SYMBOLS = [
     "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_info", "g16_msm_points",
-    "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
+    "g16_points_check_g1", "g16_points_check_g2", "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
     "g16_pkey_destroy", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
 ]
@@ -89,6 +89,8 @@ def load_library():
     lib.g16_points_count.restype = sz
     lib.g16_points_info.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     lib.g16_msm_points.argtypes = [vp, vp, vp, u32, vp]
+    lib.g16_points_check_g1.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
+    lib.g16_points_check_g2.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     lib.g16_fixed_base_g1.argtypes = [vp, vp, u32, sz, vp]
     lib.g16_fixed_base_g2.argtypes = [vp, vp, u32, sz, vp]
     lib.g16_quotient.argtypes = [vp, vp, vp, vp, u32, u32, vp]
@@ -195,6 +197,15 @@ class Context:
         flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0) | (OUT_PARTIAL if partial else 0)
         self._check(self._lib.g16_msm_points(self._h, pts._h, _buf(scalars) if pts.n else None, flags, out))
         return out.raw
+
+    def points_check(self, group: int, points: bytes):
+        """index of the first point off the curve, or None (curves.nim:95-107 mkG1/mkG2 asserts)"""
+        psz = 64 if group == 1 else 128
+        n = len(points) // psz
+        bad = ctypes.c_size_t()
+        fn = self._lib.g16_points_check_g1 if group == 1 else self._lib.g16_points_check_g2
+        self._check(fn(self._h, _buf(points) if n else None, n, ctypes.byref(bad)))
+        return None if bad.value == ctypes.c_size_t(-1).value else bad.value
 
     def fixed_base(self, group: int, scalars: bytes, mont: bool = True) -> bytes:
         """scalars[i] * generator -> affine points (fake_setup.nim:258-261 `y ** gen1/gen2`)."""

@@ -24,6 +24,7 @@ struct Xyzz {
 
 template <class F>
 struct Curve {
+  using Field = F;
   using E = typename F::T;
   using Aff = Affine<F>;
   using Acc = Xyzz<F>;

@@ -143,9 +143,21 @@ int32_t g16_msm_reduce_g1(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, c
 int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
                           const void* d_points, void* d_out_aff, void* d_out_acc);
 int32_t g16_lanes_init(g16_ctx* ctx);
+// per-curve stages of phase 2, each compiled in its own translation unit (msm_g{1,2}_{accum,reduce1,reduce2}.hip)
+#define G16_DECL_STAGES(g)                                                                                              \
+  int32_t g16_st_accum_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, const void* points, void* partial);          \
+  int32_t g16_st_heavy_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, void* partial);                              \
+  int32_t g16_st_reduce1_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, const void* partial, void* chunkR,         \
+                             void* chunkA);                                                                             \
+  int32_t g16_st_reduce2_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, const void* chunkR, const void* chunkA,    \
+                             void* wsum, void* out_aff, void* out_acc);
+G16_DECL_STAGES(g1)
+G16_DECL_STAGES(g2)
 int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 uint32_t g16_pick_window_g1(size_t n);
+int32_t g16_on_curve_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_first_bad);
+int32_t g16_on_curve_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_first_bad);
 int32_t g16_fixed_base_device_g1(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
                                  void* d_out);
 int32_t g16_fixed_base_device_g2(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,

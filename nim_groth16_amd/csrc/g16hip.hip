@@ -256,6 +256,38 @@ extern "C" int32_t g16_points_info(const g16_points* h, uint32_t* window_bits, u
   return G16_OK;
 }
 
+// on-curve check of a host point array (mkG1 / mkG2 asserts of the reference's loaders, curves.nim:95-107):
+// *first_bad = index of the first point off the curve, or SIZE_MAX if every point is on it ((0,0) = infinity ok)
+static int32_t points_check(g16_ctx* ctx, int group, const void* points, size_t n, size_t* first_bad) {
+  if (!ctx) return G16_EINVAL;
+  if (!first_bad || (n && !points) || n >= (size_t(1) << 31)) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t psz = group == 1 ? 64 : 128;
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->stage_p, n * psz + psz))) return rc;
+  if ((rc = ensure(ctx, ctx->stage_o, 2048))) return rc;
+  uint32_t* d_bad = (uint32_t*)ctx->stage_o.p;
+  HIPCHK(ctx, hipMemsetAsync(d_bad, 0xff, 4, ctx->stream));
+  if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->stage_p.p, points, n * psz, hipMemcpyHostToDevice, ctx->stream));
+  rc = group == 1 ? g16_on_curve_device_g1(ctx, ctx->stage_p.p, n, d_bad)
+                  : g16_on_curve_device_g2(ctx, ctx->stage_p.p, n, d_bad);
+  if (rc) return rc;
+  uint32_t bad = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *first_bad = bad == 0xffffffffu ? (size_t)-1 : (size_t)bad;
+  return G16_OK;
+}
+extern "C" int32_t g16_points_check_g1(g16_ctx* ctx, const void* points, size_t n, size_t* first_bad) {
+  return points_check(ctx, 1, points, n, first_bad);
+}
+extern "C" int32_t g16_points_check_g2(g16_ctx* ctx, const void* points, size_t n, size_t* first_bad) {
+  return points_check(ctx, 2, points, n, first_bad);
+}
+
 // out[i] = scalars[i] * generator  (`y ** gen1` / `y ** gen2`, fake_setup.nim:258-261); host pointers
 static int32_t fixed_base(g16_ctx* ctx, int group, const void* scalars, uint32_t flags, size_t n, void* out) {
   if (!ctx) return G16_EINVAL;

@@ -660,6 +660,21 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_precompute(const typename C::Af
   }
 }
 
+// ---- on-curve check of a point array: y^2 == x^3 + b, (0,0) = infinity is accepted ------------------------
+// the reference asserts this for every point it loads (mkG1 / mkG2, curves.nim:95-107; loadPointsG1/G2, io.nim:240-250)
+template <class C>
+__global__ void __launch_bounds__(256) points_on_curve(const typename C::Aff* __restrict__ pts, uint32_t n,
+                                                       typename C::E b, uint32_t* __restrict__ first_bad) {
+  using F = typename C::Field;
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  typename C::Aff p = pts[i];
+  if (C::is_inf(p)) return;
+  typename C::E lhs = F::sqr(p.y);
+  typename C::E rhs = F::add(F::mul(F::sqr(p.x), p.x), b);
+  if (!F::eq(lhs, rhs)) atomicMin(first_bad, i);
+}
+
 // ---- fixed-base multiples of the group generator: out[i] = k_i * G  (fake_setup.nim:258-261 `y ** gen`) ----
 // table[w*255 + d-1] = d * 2^(8w) * G, w < 32, d = 1..255 (built once per context)
 template <class C>

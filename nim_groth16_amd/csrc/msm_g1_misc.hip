@@ -1,0 +1,16 @@
+// G1 registration-time tables, fixed-base multiples of gen1, on-curve check
+#include "msm_stage.cuh"
+int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
+  return precompute_device<G1>(ctx, d_points, n, c, d_tables);
+}
+int32_t g16_fixed_base_device_g1(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
+                                 void* d_out) {
+  // gen1 = (1, 2)  (curves.nim:112-113)
+  g1_aff g{Fp::one(), Fp::dbl(Fp::one())};
+  return fixed_base_device<G1>(ctx, g, d_table, ready, d_s, mont, n, d_out);
+}
+int32_t g16_on_curve_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_first_bad) {
+  // y^2 = x^3 + 3  (curves.nim:54-67)
+  const u256 b = Fp::add(Fp::dbl(Fp::one()), Fp::one());
+  return on_curve_device<G1>(ctx, d_points, n, b, d_first_bad);
+}

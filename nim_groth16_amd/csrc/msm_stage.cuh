@@ -1,0 +1,128 @@
+// Per-curve launch templates of the accumulate / reduce stages and of the auxiliary point kernels.  Each stage is
+// instantiated in its own translation unit (msm_g1_*.hip, msm_g2_*.hip): the fully inlined G2 kernels take
+// minutes to compile, and `make -j` builds the stages in parallel.
+#pragma once
+#include "g16_internal.hpp"
+#include "msm.cuh"
+
+using namespace g16;
+
+template <class C>
+static int32_t stage_accum(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, const void* points, void* partial) {
+  const MsmParams& P = S.P;
+  const bool g2 = sizeof(typename C::Aff) == 128;
+  const uint32_t ntask = P.nbuckets + P.max_extra;
+  KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + MSM_BLOCK - 1) / MSM_BLOCK,
+             MSM_BLOCK, 0, (const typename C::Aff*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
+             (typename C::Acc*)partial);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+template <class C>
+static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, void* partial_) {
+  const MsmParams& P = S.P;
+  const bool g2 = sizeof(typename C::Aff) == 128;
+  auto* partial = (typename C::Acc*)partial_;
+  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, HEAVY_BLOCK,
+             HEAVY_BLOCK * sizeof(typename C::Acc), S.heavy, S.info, S.offset, S.xoff, P, partial);
+  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy_small<C>, 256, MSM_BLOCK, 0, S.heavy, S.info,
+             S.offset, S.xoff, P, partial);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+template <class C>
+static int32_t stage_reduce1(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, const void* partial,
+                             void* chunkR, void* chunkA) {
+  const MsmParams& P = S.P;
+  const bool g2 = sizeof(typename C::Aff) == 128;
+  const size_t nchunks = P.nbuckets / RED_CHUNK;
+  KLAUNCH_ON(ctx, st, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>,
+             (uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, (const typename C::Acc*)partial, S.offset,
+             P.nbuckets, (typename C::Acc*)chunkR, (typename C::Acc*)chunkA);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+// wsum: room for 2 * 64 + 2 accumulators
+template <class C>
+static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, const void* chunkR,
+                                  const void* chunkA, void* wsum_, void* d_out_aff, void* d_out_acc) {
+  const MsmParams& P = S.P;
+  const bool g2 = sizeof(typename C::Aff) == 128;
+  const size_t nchunks = P.nbuckets / RED_CHUNK;
+  auto* wsum = (typename C::Acc*)wsum_;
+  // reduction sets: the windows themselves, or <= 64 slices of 2048 chunks of the merged bucket set
+  uint32_t nsets = P.nwin, log2ks = 0;
+  if (P.tables) {
+    uint32_t cps = nchunks < 2048 ? (uint32_t)nchunks : 2048u;
+    nsets = (uint32_t)(nchunks / cps);
+    for (uint32_t ks = cps * RED_CHUNK; ks > 1; ks >>= 1) ++log2ks;
+  }
+  auto* wtot = wsum + 65;
+  constexpr int R2B = sizeof(typename C::Aff) == 64 ? 512 : 256;   // as wide as the register budget allows
+  KLAUNCH_ON(ctx, st, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", (msm_reduce2<C, R2B>), nsets, R2B,
+             R2B * sizeof(typename C::Acc), (const typename C::Acc*)chunkR, (const typename C::Acc*)chunkA,
+             (uint32_t)(nchunks / nsets), wsum, wtot);
+  if (P.tables)
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, 1, 64, 64 * sizeof(typename C::Acc),
+               wsum, wtot, nsets, log2ks, (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);
+  else
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets, P.c,
+               (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+// sum of XYZZ partials -> affine (the `res += sync pending[k]` of msm.nim:117-119 across GPUs)
+template <class C>
+__global__ void sum_partials_kernel(const typename C::Acc* __restrict__ parts, uint32_t count,
+                                    typename C::Aff* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  typename C::Acc r = C::acc_inf();
+  for (uint32_t i = 0; i < count; ++i) C::add(r, parts[i]);
+  *out = C::to_affine(r);
+}
+
+template <class C>
+static int32_t sum_partials_device(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff) {
+  KLAUNCH(ctx, "sum_partials", sum_partials_kernel<C>, 1, 64, 0, (const typename C::Acc*)d_parts, count,
+          (typename C::Aff*)d_out_aff);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+template <class C>
+static int32_t precompute_device(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
+  const uint32_t nwin = FR_BITS / c + 1;
+  KLAUNCH(ctx, "msm_precompute", msm_precompute<C>, (uint32_t)((n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0,
+          (const typename C::Aff*)d_points, (uint32_t)n, c, nwin, (typename C::Aff*)d_tables);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+// gen: group generator in Montgomery affine form; d_table: 32*255 points (built here when !table_ready)
+template <class C>
+static int32_t fixed_base_device(g16_ctx* ctx, const typename C::Aff& gen, void* d_table, bool table_ready,
+                                 const void* d_scalars, uint32_t mont, size_t n, void* d_out) {
+  if (!table_ready)
+    KLAUNCH(ctx, "fixed_base_table", fixed_base_table<C>, (32 * 255 + 255) / 256, 256, 0, gen,
+            (typename C::Aff*)d_table);
+  if (n)
+    KLAUNCH(ctx, "fixed_base_mul", fixed_base_mul<C>, (uint32_t)((n + 255) / 256), 256, 0, (const u256*)d_scalars,
+            mont, (uint32_t)n, (const typename C::Aff*)d_table, (typename C::Aff*)d_out);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+// first_bad (device u32) must hold 0xffffffff on entry
+template <class C>
+static int32_t on_curve_device(g16_ctx* ctx, const void* d_points, size_t n, const typename C::E& b,
+                               uint32_t* d_first_bad) {
+  if (n)
+    KLAUNCH(ctx, "points_on_curve", points_on_curve<C>, (uint32_t)((n + 255) / 256), 256, 0,
+            (const typename C::Aff*)d_points, (uint32_t)n, b, d_first_bad);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}

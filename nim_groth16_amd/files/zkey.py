@@ -15,7 +15,20 @@ from .container import parseContainer, parsePrimeField, writeContainer
 _R = F.primeR
 
 
-def parseZKey(fname: str) -> ZKey:
+def checkZKeyPoints(zk: ZKey, ctx=None) -> None:
+    """The reference asserts that every loaded point lies on its curve (mkG1/mkG2, curves.nim:95-107).  Here the
+    check is one GPU pass per section, run on request (parseZKey(..., check=True))."""
+    from .._lib import default_context
+    ctx = ctx or default_context()
+    sp, pp = zk.specPoints, zk.pPoints
+    for name, group, buf in (("spec G1", 1, sp.alpha1 + sp.beta1 + sp.delta1), ("spec G2", 2, sp.beta2 + sp.gamma2 + sp.delta2),
+                             ("pointsIC", 1, zk.pointsIC), ("pointsA1", 1, pp.pointsA1), ("pointsB1", 1, pp.pointsB1),
+                             ("pointsB2", 2, pp.pointsB2), ("pointsC1", 1, pp.pointsC1), ("pointsH1", 1, pp.pointsH1)):
+        bad = ctx.points_check(group, buf)
+        assert bad is None, f"mkG{group}: {name}[{bad}] is not a G{group} curve point"
+
+
+def parseZKey(fname: str, check: bool = False, ctx=None) -> ZKey:
     """zkey.nim:241-246"""
     sec = parseContainer("zkey", 1, fname)
     one = lambda i: sec[i][0]                                            # noqa: E731
@@ -66,6 +79,8 @@ def parseZKey(fname: str) -> ZKey:
         v = int.from_bytes(raw[32 * i:32 * i + 32], "little")
         coeffs.append((ms[i], rs[i], cs[i], (v * F.frInvMontR % _R).to_bytes(32, "little")))
     zk.coeffs = coeffs
+    if check:
+        checkZKeyPoints(zk, ctx)
     return zk
 
 

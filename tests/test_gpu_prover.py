@@ -180,3 +180,106 @@ def test_files_to_proof_json_end_to_end(ctx, tmp_path):
                   (int(dj["pi_c"][0]), int(dj["pi_c"][1])))
     assert (got.pi_a, got.pi_b, got.pi_c, got.publicIO) == (ref.pi_a, ref.pi_b, ref.pi_c, ref.publicIO)
     assert o.verify_proof(oz, got)
+
+
+def _oracle_setup(r1cs_o, tox, flavour, orc):
+    bg1 = lambda ks: [o.g1_from_bytes(x) for x in _chunks(orc.fixed_base(1, I.fr_mont_bytes(ks)), 64)]    # noqa: E731
+    bg2 = lambda ks: [o.g2_from_bytes(x) for x in _chunks(orc.fixed_base(2, I.fr_mont_bytes(ks)), 128)]   # noqa: E731
+    return o.fake_circuit_setup(r1cs_o, tox, flavour, bg1, bg2)
+
+
+def _oracle_prove(oz, wit, r, s, orc):
+    msm1 = lambda cs, ps: o.g1_from_bytes(orc.msm(1, I.fr_mont_bytes(cs), b"".join(map(o.g1_to_bytes, ps)))) if cs else o.INF_G1   # noqa: E731
+    msm2 = lambda cs, ps: o.g2_from_bytes(orc.msm(2, I.fr_mont_bytes(cs), b"".join(map(o.g2_to_bytes, ps)))) if cs else o.INF_G2   # noqa: E731
+    return o.generate_proof_with_mask(oz, wit, r, s, msm_g1=msm1, msm_g2=msm2)
+
+
+@pytest.mark.parametrize("case", ["no_public_signals", "all_wires_public", "tiny_domain", "jensgroth_mid",
+                                  "sparse_zero_witness"])
+def test_prover_shape_edge_cases(ctx, orc, case):
+    """shapes at the edges of generateProofWithMask's asserts (prover.nim:236, 270-276): npubs = 0; an empty
+    pointsC1 (nvars = npubs+1); the smallest domains; the JensGroth flavour beyond the toy size (7 NTTs,
+    prover.nim:118-148); a witness that is almost all zeros (empty buckets everywhere)."""
+    from nim_groth16_amd import Mask, Witness, generateProofWithMask, loadProvingKey
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import squaringChain
+    a, b, g, d, t = _toxic(31)
+    flavour = 1
+    if case == "no_public_signals":          # x*x = y with nothing public: npubs = 0 -> domain from 1+0+1
+        cons = [([(1, 1)], [(1, 1)], [(2, 1)])]
+        r1, wit = R1CS(3, 0, 0, 1, cons), [1, 5, 25]
+    elif case == "all_wires_public":         # nvars = npubs + 1: pointsC1 is empty, zs = []
+        cons = [([(1, 1)], [(1, 1)], [(2, 1)])]
+        r1, wit = R1CS(3, 1, 1, 0, cons), [1, 7, 49]
+    elif case == "tiny_domain":              # one constraint, one public output -> domain 4
+        cons = [([(2, 1)], [(2, 1)], [(1, 1)])]
+        r1, wit = R1CS(3, 1, 0, 1, cons), [1, 81, 9]
+    elif case == "jensgroth_mid":
+        r1, wit = squaringChain((1 << 7) - 2, seed=8)
+        flavour = 0
+    else:                                    # chain started at 0 with k_i = 0 is impossible (k random); zero most wires instead
+        m = (1 << 6) - 2
+        cons = [([(i + 2, 1)], [(i + 2, 1)], [((i + 3) if i + 1 < m else 1, 1)]) for i in range(m)]
+        r1, wit = R1CS(m + 2, 1, 0, 1, cons), [1] + [0] * (m + 1)
+    zk = fakeCircuitSetup(r1, ToxicWaste(a, b, g, d, t), flavour, ctx)
+    oz = _oracle_setup(o.R1CS(r1.nWires, r1.nPubOut, r1.nPubIn, r1.nPrivIn, r1.constraints),
+                       o.ToxicWaste(a, b, g, d, t), o.SNARKJS if flavour else o.JENS_GROTH, orc)
+    # the witness satisfies the circuit
+    for (A, B, C) in r1.constraints:
+        ev = lambda lc: sum(v * wit[w] for w, v in lc) % o.R        # noqa: E731
+        assert ev(A) * ev(B) % o.R == ev(C)
+    pk = loadProvingKey(zk, ctx)
+    rng = o.SplitMix64(32)
+    for (r, s) in ((0, 0), (rng.fr(), rng.fr())):
+        pr = generateProofWithMask(0, False, zk, Witness("bn128", r1.nWires, I.fr_mont_bytes(wit)), Mask(r, s), ctx, pkey=pk)
+        ref = _oracle_prove(oz, wit, r, s, orc)
+        assert (o.g1_from_bytes(pr.pi_a), o.g2_from_bytes(pr.pi_b), o.g1_from_bytes(pr.pi_c)) == \
+            (ref.pi_a, ref.pi_b, ref.pi_c), case
+        assert o.verify_proof(oz, ref), case
+    pk.destroy()
+
+
+def test_prover_rejects_bad_shapes(ctx):
+    """error convention at the boundary: bad arguments come back as G16_EINVAL / AssertionError, never a crash"""
+    from nim_groth16_amd import G16Error, Mask, Witness, generateProofWithMask
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.zkey_types import MatrixC
+    a, b, g, d, t = _toxic(41)
+    toy = o.toy_r1cs()
+    zk = fakeCircuitSetup(R1CS(8, 1, 1, 3, toy.constraints), ToxicWaste(a, b, g, d, t), 1, ctx)
+    with pytest.raises(AssertionError):       # prover.nim:236 "wrong witness length"
+        generateProofWithMask(0, False, zk, Witness("bn128", 7, I.fr_mont_bytes(o.TOY_WITNESS[:7])), Mask(0, 0), ctx)
+    with pytest.raises(AssertionError):       # prover.nim:224 curve mismatch
+        generateProofWithMask(0, False, zk, Witness("bls12", 8, I.fr_mont_bytes(o.TOY_WITNESS)), Mask(0, 0), ctx)
+    import copy
+    bad = copy.deepcopy(zk)
+    bad.coeffs = list(bad.coeffs) + [(MatrixC, 0, 0, o.fr_to_mont_bytes(1))]
+    from nim_groth16_amd import loadProvingKey
+    with pytest.raises(G16Error) as e:        # MatrixC entries make buildABC raise (prover.nim:67)
+        loadProvingKey(bad, ctx)
+    assert e.value.code == -1
+
+
+def test_zkey_point_check_on_gpu(ctx, tmp_path):
+    """mkG1 / mkG2 on-curve asserts of the reference's loaders (curves.nim:95-107) as a GPU pass"""
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.files import parseZKey, writeZKey
+    a, b, g, d, t = _toxic(51)
+    zk = fakeCircuitSetup(R1CS(8, 1, 1, 3, o.toy_r1cs().constraints), ToxicWaste(a, b, g, d, t), 1, ctx)
+    path = str(tmp_path / "k.zkey")
+    writeZKey(path, zk)
+    assert parseZKey(path, check=True, ctx=ctx) == zk
+    pts = bytearray(zk.pPoints.pointsB2)
+    assert ctx.points_check(2, bytes(pts)) is None
+    pts[128 * 3 + 5] ^= 1                                    # corrupt point 3
+    assert ctx.points_check(2, bytes(pts)) == 3
+    g1 = bytearray(zk.pPoints.pointsA1)
+    assert ctx.points_check(1, bytes(g1) + bytes(64)) is None   # (0,0) = infinity is accepted (curves.nim:96-98)
+    g1[64 * 5 + 40] ^= 0x80
+    assert ctx.points_check(1, bytes(g1)) == 5
+    assert ctx.points_check(1, b"") is None
+    import dataclasses
+    bad = dataclasses.replace(zk, pPoints=dataclasses.replace(zk.pPoints, pointsA1=bytes(g1)))
+    writeZKey(path, bad)
+    with pytest.raises(AssertionError):
+        parseZKey(path, check=True, ctx=ctx)
