@@ -14,6 +14,15 @@ def _header_symbols():
     return sorted(set(re.findall(r"\b(g16_[a-z0-9_]+)\s*\(", text)))
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _library_built():
+    """the shared library is a build artefact (git-ignored): build it when the tree is fresh"""
+    from nim_groth16_amd._lib import lib_path
+    if not os.path.exists(lib_path()):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "nim_groth16_amd", "csrc"), "-j", "8"])
+
+
 def test_library_exports_every_declared_symbol():
     from nim_groth16_amd._lib import SYMBOLS, load_library
     lib = load_library()
