@@ -49,7 +49,7 @@ struct Curve {
     E xx = F::sqr(p.x);
     E m = F::add(F::dbl(xx), xx);
     E x3 = F::sub(F::sqr(m), F::dbl(s));
-    E y3 = F::sub(F::mul(m, F::sub(s, x3)), F::mul(w, p.y));
+    E y3 = F::mulsub(m, F::sub(s, x3), w, p.y);
     return Acc{x3, y3, v, w};  // y == 0 would give zz = 0 = infinity (cannot happen: odd order)
   }
   // 2*P  (dbl-2008-s-1)
@@ -62,7 +62,7 @@ struct Curve {
     E xx = F::sqr(p.x);
     E m = F::add(F::dbl(xx), xx);
     E x3 = F::sub(F::sqr(m), F::dbl(s));
-    E y3 = F::sub(F::mul(m, F::sub(s, x3)), F::mul(w, p.y));
+    E y3 = F::mulsub(m, F::sub(s, x3), w, p.y);
     return Acc{x3, y3, F::mul(v, p.zz), F::mul(w, p.zzz)};
   }
   // acc += q (affine)   (madd-2008-s)
@@ -85,7 +85,7 @@ struct Curve {
     E ppp = F::mul(p, pp);
     E qq = F::mul(acc.x, pp);
     E x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
-    E y3 = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(acc.y, ppp));
+    E y3 = F::mulsub(r, F::sub(qq, x3), acc.y, ppp);
     acc.x = x3;
     acc.y = y3;
     acc.zz = F::mul(acc.zz, pp);
@@ -113,7 +113,7 @@ struct Curve {
     E ppp = F::mul(p, pp);
     E qq = F::mul(u1, pp);
     E x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
-    E y3 = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(s1, ppp));
+    E y3 = F::mulsub(r, F::sub(qq, x3), s1, ppp);
     acc.x = x3;
     acc.y = y3;
     acc.zz = F::mul(F::mul(acc.zz, q.zz), pp);

@@ -40,10 +40,6 @@ struct alignas(16) u256 {
   uint32_t v[8];
 };
 
-struct alignas(16) u512 {
-  uint32_t v[16];
-};
-
 // ---- 96-bit column accumulator primitives -------------------------------------------------------
 // (lo:64, hi:32) += a*b
 FF_HD void mac(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
@@ -310,88 +306,95 @@ struct Field {
   }
   static FF_HD T to_mont(const T& a) { return mul(a, r2()); }
 
-  // ---- double-width arithmetic for lazy reduction (used by Fp2::mul) ---------------------------------------
-  // a + b without the conditional subtraction (result < 2p when a, b < p)
-  static FF_HD T add_noreduce(const T& a, const T& b) {
-    T s;
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s.v[i] = addc(a.v[i], b.v[i], c);
-    return s;
-  }
+  // ---- Montgomery dot product  (a*b + c*d) / R mod p  in ONE interleaved product-scanning pass --------------
+  // Used by Fp2::mul: both components of an Fp2 product are sums of two base-field products, so they need one
+  // reduction each instead of three for Karatsuba -- and no additions or subtractions around the products.
+  // Column sums hold up to 24 partial products (< 2^69): the 96-bit accumulator suffices.  Operands <= p give a
+  // result < p (2p/R + 1) < 2p, made canonical by one conditional subtraction.
   template <int K>
-  static FF_HD void wide_col(uint64_t& lo, uint32_t& hi, const T& a, const T& b, u512& r) {
-    constexpr int S = K < 8 ? 0 : K - 7, N = K < 8 ? K + 1 : 15 - K;
-    col_ab<K, S>(lo, hi, a, b, std::make_integer_sequence<int, N>{});
-    r.v[K] = (uint32_t)lo;
-    acc_shift(lo, hi);
-  }
-  // full 512-bit product a*b (no reduction): 64 v_mad_u64_u32 + 64 v_addc
-  static FF_HD u512 mul_wide(const T& a, const T& b) {
-    u512 r;
-    uint64_t lo = 0;
-    uint32_t hi = 0;
-    wide_col<0>(lo, hi, a, b, r); wide_col<1>(lo, hi, a, b, r); wide_col<2>(lo, hi, a, b, r);
-    wide_col<3>(lo, hi, a, b, r); wide_col<4>(lo, hi, a, b, r); wide_col<5>(lo, hi, a, b, r);
-    wide_col<6>(lo, hi, a, b, r); wide_col<7>(lo, hi, a, b, r); wide_col<8>(lo, hi, a, b, r);
-    wide_col<9>(lo, hi, a, b, r); wide_col<10>(lo, hi, a, b, r); wide_col<11>(lo, hi, a, b, r);
-    wide_col<12>(lo, hi, a, b, r); wide_col<13>(lo, hi, a, b, r); wide_col<14>(lo, hi, a, b, r);
-    r.v[15] = (uint32_t)lo;
-    return r;
-  }
-  static FF_HD u512 add_wide(const u512& a, const u512& b) {
-    u512 r;
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.v[i] = addc(a.v[i], b.v[i], c);
-    return r;
-  }
-  // r = a - b, returns the borrow
-  static FF_HD uint32_t sub_wide(u512& r, const u512& a, const u512& b) {
-    uint32_t bw = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.v[i] = subc(a.v[i], b.v[i], bw);
-    return bw;
-  }
-  // r += p * 2^256 if flag (brings a difference of two products back into [0, p*R))
-  static FF_HD void add_pR_if(u512& r, uint32_t flag) {
-    const uint32_t mask = flag ? 0xffffffffu : 0u;
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[8 + i] = addc(r.v[8 + i], Pi(i) & mask, c);
-  }
-  // Montgomery reduction of a 512-bit value x < p*R:  x / R mod p, canonical
-  template <int K>
-  static FF_HD void redc_col_lo(uint64_t& lo, uint32_t& hi, const u512& x, uint32_t (&m)[8]) {
+  static FF_HD void mul2_col_lo(uint64_t& lo, uint32_t& hi, const T& a, const T& b, const T& c, const T& d,
+                                uint32_t (&m)[8]) {
+    col_ab<K, 0>(lo, hi, a, b, std::make_integer_sequence<int, K + 1>{});
+    col_ab<K, 0>(lo, hi, c, d, std::make_integer_sequence<int, K + 1>{});
     if constexpr (K > 0) col_mp<K, 0>(lo, hi, m, std::make_integer_sequence<int, K>{});
-    uint64_t old = lo;
-    lo += x.v[K];
-    hi += (lo < old) ? 1u : 0u;
     m[K] = (uint32_t)lo * PR::INV;
     macs(lo, hi, m[K], P<0>());
     acc_shift(lo, hi);
   }
   template <int K>
-  static FF_HD void redc_col_hi(uint64_t& lo, uint32_t& hi, const u512& x, const uint32_t (&m)[8], T& r) {
-    if constexpr (K < 15) col_mp<K, K - 7>(lo, hi, m, std::make_integer_sequence<int, 15 - K>{});
-    uint64_t old = lo;
-    lo += x.v[K];
-    hi += (lo < old) ? 1u : 0u;
+  static FF_HD void mul2_col_hi(uint64_t& lo, uint32_t& hi, const T& a, const T& b, const T& c, const T& d,
+                                const uint32_t (&m)[8], T& r) {
+    if constexpr (K < 15) {
+      col_ab<K, K - 7>(lo, hi, a, b, std::make_integer_sequence<int, 15 - K>{});
+      col_ab<K, K - 7>(lo, hi, c, d, std::make_integer_sequence<int, 15 - K>{});
+      col_mp<K, K - 7>(lo, hi, m, std::make_integer_sequence<int, 15 - K>{});
+    }
     r.v[K - 8] = (uint32_t)lo;
     acc_shift(lo, hi);
   }
-  static FF_HD T redc(const u512& x) {
+  static FF_HD T mul2(const T& a, const T& b, const T& c, const T& d) {
     uint32_t m[8];
     T r;
     uint64_t lo = 0;
     uint32_t hi = 0;
-    redc_col_lo<0>(lo, hi, x, m); redc_col_lo<1>(lo, hi, x, m); redc_col_lo<2>(lo, hi, x, m);
-    redc_col_lo<3>(lo, hi, x, m); redc_col_lo<4>(lo, hi, x, m); redc_col_lo<5>(lo, hi, x, m);
-    redc_col_lo<6>(lo, hi, x, m); redc_col_lo<7>(lo, hi, x, m);
-    redc_col_hi<8>(lo, hi, x, m, r); redc_col_hi<9>(lo, hi, x, m, r); redc_col_hi<10>(lo, hi, x, m, r);
-    redc_col_hi<11>(lo, hi, x, m, r); redc_col_hi<12>(lo, hi, x, m, r); redc_col_hi<13>(lo, hi, x, m, r);
-    redc_col_hi<14>(lo, hi, x, m, r); redc_col_hi<15>(lo, hi, x, m, r);
-    return reduce_once(r);   // x < p*R  =>  (x + m p)/R < 2p
+    mul2_col_lo<0>(lo, hi, a, b, c, d, m); mul2_col_lo<1>(lo, hi, a, b, c, d, m);
+    mul2_col_lo<2>(lo, hi, a, b, c, d, m); mul2_col_lo<3>(lo, hi, a, b, c, d, m);
+    mul2_col_lo<4>(lo, hi, a, b, c, d, m); mul2_col_lo<5>(lo, hi, a, b, c, d, m);
+    mul2_col_lo<6>(lo, hi, a, b, c, d, m); mul2_col_lo<7>(lo, hi, a, b, c, d, m);
+    mul2_col_hi<8>(lo, hi, a, b, c, d, m, r); mul2_col_hi<9>(lo, hi, a, b, c, d, m, r);
+    mul2_col_hi<10>(lo, hi, a, b, c, d, m, r); mul2_col_hi<11>(lo, hi, a, b, c, d, m, r);
+    mul2_col_hi<12>(lo, hi, a, b, c, d, m, r); mul2_col_hi<13>(lo, hi, a, b, c, d, m, r);
+    mul2_col_hi<14>(lo, hi, a, b, c, d, m, r); mul2_col_hi<15>(lo, hi, a, b, c, d, m, r);
+    return reduce_once(r);
+  }
+  // four-term dot product (a*b + c*d + e*f + g*h) / R mod p  (column sums < 2^70; result < p (4p/R + 1) < 2p)
+  template <int K>
+  static FF_HD void mul4_col_lo(uint64_t& lo, uint32_t& hi, const T* x, uint32_t (&m)[8]) {
+    col_ab<K, 0>(lo, hi, x[0], x[1], std::make_integer_sequence<int, K + 1>{});
+    col_ab<K, 0>(lo, hi, x[2], x[3], std::make_integer_sequence<int, K + 1>{});
+    col_ab<K, 0>(lo, hi, x[4], x[5], std::make_integer_sequence<int, K + 1>{});
+    col_ab<K, 0>(lo, hi, x[6], x[7], std::make_integer_sequence<int, K + 1>{});
+    if constexpr (K > 0) col_mp<K, 0>(lo, hi, m, std::make_integer_sequence<int, K>{});
+    m[K] = (uint32_t)lo * PR::INV;
+    macs(lo, hi, m[K], P<0>());
+    acc_shift(lo, hi);
+  }
+  template <int K>
+  static FF_HD void mul4_col_hi(uint64_t& lo, uint32_t& hi, const T* x, const uint32_t (&m)[8], T& r) {
+    if constexpr (K < 15) {
+      col_ab<K, K - 7>(lo, hi, x[0], x[1], std::make_integer_sequence<int, 15 - K>{});
+      col_ab<K, K - 7>(lo, hi, x[2], x[3], std::make_integer_sequence<int, 15 - K>{});
+      col_ab<K, K - 7>(lo, hi, x[4], x[5], std::make_integer_sequence<int, 15 - K>{});
+      col_ab<K, K - 7>(lo, hi, x[6], x[7], std::make_integer_sequence<int, 15 - K>{});
+      col_mp<K, K - 7>(lo, hi, m, std::make_integer_sequence<int, 15 - K>{});
+    }
+    r.v[K - 8] = (uint32_t)lo;
+    acc_shift(lo, hi);
+  }
+  static FF_HD T mul4(const T& a, const T& b, const T& c, const T& d, const T& e, const T& f, const T& g, const T& h) {
+    const T x[8] = {a, b, c, d, e, f, g, h};
+    uint32_t m[8];
+    T r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    mul4_col_lo<0>(lo, hi, x, m); mul4_col_lo<1>(lo, hi, x, m); mul4_col_lo<2>(lo, hi, x, m);
+    mul4_col_lo<3>(lo, hi, x, m); mul4_col_lo<4>(lo, hi, x, m); mul4_col_lo<5>(lo, hi, x, m);
+    mul4_col_lo<6>(lo, hi, x, m); mul4_col_lo<7>(lo, hi, x, m);
+    mul4_col_hi<8>(lo, hi, x, m, r); mul4_col_hi<9>(lo, hi, x, m, r); mul4_col_hi<10>(lo, hi, x, m, r);
+    mul4_col_hi<11>(lo, hi, x, m, r); mul4_col_hi<12>(lo, hi, x, m, r); mul4_col_hi<13>(lo, hi, x, m, r);
+    mul4_col_hi<14>(lo, hi, x, m, r); mul4_col_hi<15>(lo, hi, x, m, r);
+    return reduce_once(r);
+  }
+  // a*b - c*d  in one Montgomery pass (the Y3 line of every addition / doubling formula)
+  static FF_HD T mulsub(const T& a, const T& b, const T& c, const T& d) { return mul2(a, b, neg_raw(c), d); }
+
+  // p - a as a plain integer (a <= p): a representative of -a in [0, p] (p itself for a = 0), fine as a mul2 operand
+  static FF_HD T neg_raw(const T& a) {
+    T r;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = subc(Pi(i), a.v[i], bw);
+    return r;
   }
 
   // a^e for a 256-bit exponent given as 8 limbs (vartime; exponents here are public constants)
@@ -504,22 +507,16 @@ struct Fp2 {
   static FF_HD T sub(const T& a, const T& b) { return T{Fp::sub(a.c0, b.c0), Fp::sub(a.c1, b.c1)}; }
   static FF_HD T neg(const T& a) { return T{Fp::neg(a.c0), Fp::neg(a.c1)}; }
   static FF_HD T dbl(const T& a) { return T{Fp::dbl(a.c0), Fp::dbl(a.c1)}; }
-  // Karatsuba with lazy reduction: 3 double-width products, 2 Montgomery reductions (instead of 3 + 3):
-  //   c0 = redc(a0 b0 - a1 b1 [+ pR if negative]),   c1 = redc((a0+a1)(b0+b1) - a0 b0 - a1 b1)
-  // bounds: operands < 2p, products < 4p^2 < 2^512; both redc inputs lie in [0, pR).
+  // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u : two Montgomery dot products (Fp::mul2)
   static FF_HD_CALL T mul(const T& a, const T& b) {
-    const u512 t0 = Fp::mul_wide(a.c0, b.c0);
-    const u512 t1 = Fp::mul_wide(a.c1, b.c1);
-    u512 d;
-    const uint32_t neg = Fp::sub_wide(d, t0, t1);
-    Fp::add_pR_if(d, neg);
-    T r;
-    r.c0 = Fp::redc(d);
-    const u512 t2 = Fp::mul_wide(Fp::add_noreduce(a.c0, a.c1), Fp::add_noreduce(b.c0, b.c1));
-    u512 e;
-    (void)Fp::sub_wide(e, t2, Fp::add_wide(t0, t1));   // = a0 b1 + a1 b0 >= 0
-    r.c1 = Fp::redc(e);
-    return r;
+    return T{Fp::mul2(a.c0, b.c0, Fp::neg_raw(a.c1), b.c1), Fp::mul2(a.c0, b.c1, a.c1, b.c0)};
+  }
+  // a*b - c*d over Fp2: each component is a four-term dot product
+  //   re = a0 b0 - a1 b1 - c0 d0 + c1 d1 ,   im = a0 b1 + a1 b0 - c0 d1 - c1 d0
+  static FF_HD_CALL T mulsub(const T& a, const T& b, const T& c, const T& d) {
+    const u256 na1 = Fp::neg_raw(a.c1), nc0 = Fp::neg_raw(c.c0), nc1 = Fp::neg_raw(c.c1);
+    return T{Fp::mul4(a.c0, b.c0, na1, b.c1, nc0, d.c0, c.c1, d.c1),
+             Fp::mul4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
   }
   // complex squaring: 2 base-field products
   static FF_HD_CALL T sqr(const T& a) {

@@ -101,6 +101,7 @@ struct HFp {
     return r;
   }
   static T sqr(const T& a) { return mul(a, a); }
+  static T mulsub(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
   static T inv(const T& a) {  // a^(p-2)
     uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
     T acc = one(), base = a;
@@ -137,6 +138,7 @@ struct HFp2 {
     h256 s = HFp::mul(HFp::add(a.c0, a.c1), HFp::add(b.c0, b.c1));
     return T{HFp::sub(v0, v1), HFp::sub(HFp::sub(s, v0), v1)};
   }
+  static T mulsub(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
   static T sqr(const T& a) {
     h256 t = HFp::mul(a.c0, a.c1);
     return T{HFp::mul(HFp::add(a.c0, a.c1), HFp::sub(a.c0, a.c1)), HFp::dbl(t)};
