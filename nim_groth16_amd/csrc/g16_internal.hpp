@@ -143,6 +143,7 @@ int32_t g16_msm_reduce_g1(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, c
 int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
                           const void* d_points, void* d_out_aff, void* d_out_acc);
 int32_t g16_lanes_init(g16_ctx* ctx);
+int g16_stream_priority(int index);
 // per-curve stages of phase 2, each compiled in its own translation unit (msm_g{1,2}_{accum,reduce1,reduce2}.hip)
 #define G16_DECL_STAGES(g)                                                                                              \
   int32_t g16_st_accum_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, const void* points, void* partial);          \
