@@ -21,6 +21,9 @@
 namespace g16 {
 
 constexpr int MSM_BLOCK = 256;
+#ifndef G16_G2_WAVES
+#define G16_G2_WAVES 2
+#endif
 constexpr int FR_BITS = 254;
 
 
@@ -430,7 +433,7 @@ __device__ __forceinline__ typename C::Aff load_point(const typename C::Aff* __r
 // occupancy target: G1 fits 4 waves/SIMD (<=128 VGPRs); G2 needs ~260 registers unconstrained, which would
 // drop it to 1 wave/SIMD -- bound it to 256 (2 waves/SIMD)
 template <class C>
-__global__ void __launch_bounds__(MSM_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : 2) msm_accum(const typename C::Aff* __restrict__ points,
+__global__ void __launch_bounds__(MSM_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : G16_G2_WAVES) msm_accum(const typename C::Aff* __restrict__ points,
                                                        const uint32_t* __restrict__ entries,
                                                        const uint32_t* __restrict__ offset,
                                                        const uint2* __restrict__ xseg,
