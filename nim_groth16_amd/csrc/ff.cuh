@@ -33,6 +33,11 @@
 #define FF_HD inline __attribute__((always_inline))
 #define FF_HD_CALL inline
 #endif
+#if defined(__HIPCC__)
+#define FF_HD_COLD __host__ __device__ __attribute__((noinline))   // rarely taken paths: keep them out of line
+#else
+#define FF_HD_COLD __attribute__((noinline))
+#endif
 
 namespace g16 {
 

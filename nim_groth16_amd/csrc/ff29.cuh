@@ -1,0 +1,264 @@
+// BN254 Fp in reduced radix for the bucket-accumulation kernels: 9 limbs of 29 bits, Montgomery radix 2^261.
+//
+// Why: on gfx950 a 32x32->64 multiply-add (v_mad_u64_u32) issues in ~4.9 cycles/wave and every carry
+// instruction behind it (v_addc_co_u32) in ~4.3 (profiles/r01_ubench_int_issue_rates.txt).  With full 32-bit
+// limbs (ff.cuh) every partial product needs one of each.  With 29-bit limbs a whole column of the product
+// (<= 9 a_i*b_j plus 9 m_i*p_j) fits the 64-bit accumulator of v_mad_u64_u32, so a column is a carry-free
+// chain of multiply-adds followed by one 64-bit shift: 1161 -> 908 SIMD cycles per wave-multiplication
+// measured (tools/ubench_mul29.hip), and a dedicated squaring and multi-term dot products come for free.
+//
+// Values are lazily reduced: limbs may exceed 29 bits and values may exceed p, within bounds that are stated
+// at each function and PROVEN for the two mixed-addition sequences by the interval model tools/ff29_model.py
+// (it executes the same operation sequence on worst-case bounds and checks every 64-bit column, every 32-bit
+// limb and the loop invariant).  "normalized" = limbs 0..7 < 2^29; the top limb carries whatever is left.
+//
+// The representation never leaves the accumulate kernel family: point tables are converted once at
+// registration (Ec29::from_std) and bucket sums are converted back to the 8x32 / R=2^256 layout of ff.cuh
+// (Ec29::to_std) before the reduction kernels see them.
+#pragma once
+#include "ff.cuh"
+
+namespace g16 {
+
+struct fe29 {
+  uint32_t v[9];
+};
+
+struct Fp29 {
+  static constexpr int B = 29, L = 9;
+  static constexpr uint32_t MASK = (1u << B) - 1;
+  static constexpr uint32_t N0 = 0x4866389u;      // -p^-1 mod 2^29
+  static constexpr uint32_t PINV0 = 0x1b799c77u;  //  p^-1 mod 2^29
+  struct Limbs {
+    uint32_t v[9];
+  };
+  static constexpr Limbs PL = {{0x187cfd47u, 0x10460b6u, 0x1c72a34fu, 0x2d522d0u, 0x1585d978u, 0x2db40c0u,
+                                0xa6e141u, 0xe5c2634u, 0x30644eu}};
+  static constexpr Limbs ONE = {{0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x14c0419u, 0xaa36fb9u, 0x1d4240ceu,
+                                 0x11d54c07u, 0x52ac7a8u, 0xdc836u}};  // 2^261 mod p
+  static constexpr Limbs C_IN = {{0x13349ca1u, 0x1a5d84a8u, 0xa3e5cacu, 0x100249e0u, 0x12b951e8u, 0xe92d304u,
+                                  0x14cb95b3u, 0x41b9d3du, 0x58003u}};  // 2^266 mod p: x*2^256 -> x*2^261
+  static constexpr Limbs C_OUT = {{0x58f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu,
+                                   0x1cbd99bau, 0x183340fbu, 0xe0a77u}};  // 2^256 mod p: x*2^261 -> x*2^256
+
+  // limbs of MULT*p with LIFT units borrowed from every higher limb into the one below ("borrow form"):
+  // same value, but limbs 0..7 >= LIFT*(2^29-1), so that  a + K - b  stays non-negative limb by limb
+  template <uint32_t MULT, uint32_t LIFT>
+  static constexpr Limbs kform() {
+    Limbs k{};
+    uint64_t carry = 0;
+    for (int i = 0; i < L; ++i) {
+      uint64_t t = (uint64_t)PL.v[i] * MULT + carry;
+      k.v[i] = i < L - 1 ? (uint32_t)(t & MASK) : (uint32_t)t;
+      carry = t >> B;
+    }
+    for (int i = 0; i < L - 1; ++i) {
+      k.v[i] += LIFT << B;
+      k.v[i + 1] -= LIFT;
+    }
+    return k;
+  }
+
+  static FF_HD fe29 zero() {
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = 0;
+    return r;
+  }
+  static FF_HD fe29 one() {
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = ONE.v[i];
+    return r;
+  }
+  static FF_HD fe29 constant(const Limbs& c) {
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = c.v[i];
+    return r;
+  }
+  static FF_HD bool limbs_zero(const fe29& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) o |= a.v[i];
+    return o == 0;
+  }
+
+  // (sum over NP pairs of a_j*b_j) / 2^261 mod p.  Every 64-bit column sum must stay below 2^64: with limb
+  // bounds la_j, lb_j that is  9*(sum_j la_j*lb_j + 2^58) < 2^64.  Result: normalized, < (sum a_j b_j)/2^261 + p.
+  template <int NP>
+  static FF_HD fe29 dot(const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1, const fe29& a2,
+                        const fe29& b2, const fe29& a3, const fe29& b3) {
+    uint32_t m[L];
+    fe29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; ++k) {
+      const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) {
+        acc += (uint64_t)a0.v[i] * b0.v[k - i];
+        if constexpr (NP > 1) acc += (uint64_t)a1.v[i] * b1.v[k - i];
+        if constexpr (NP > 2) acc += (uint64_t)a2.v[i] * b2.v[k - i];
+        if constexpr (NP > 3) acc += (uint64_t)a3.v[i] * b3.v[k - i];
+      }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i)
+        if (!(k < L && i == k)) acc += (uint64_t)m[i] * PL.v[k - i];
+      if (k < L) {
+        m[k] = ((uint32_t)acc * N0) & MASK;
+        acc += (uint64_t)m[k] * PL.v[0];
+      } else {
+        r.v[k - L] = (uint32_t)acc & MASK;
+      }
+      acc >>= B;
+    }
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+  }
+  static FF_HD fe29 mul(const fe29& a, const fe29& b) { return dot<1>(a, b, a, b, a, b, a, b); }
+  static FF_HD fe29 dot2(const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1) {
+    return dot<2>(a0, b0, a1, b1, a0, b0, a0, b0);
+  }
+  static FF_HD fe29 dot4(const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1, const fe29& a2,
+                         const fe29& b2, const fe29& a3, const fe29& b3) {
+    return dot<4>(a0, b0, a1, b1, a2, b2, a3, b3);
+  }
+  // a^2 / 2^261: the cross products once, against the doubled operand (45 + 81 multiply-adds instead of 162)
+  static FF_HD fe29 sqr(const fe29& a) {
+    uint32_t m[L], a2[L];
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) a2[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; ++k) {
+      const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) {
+        if (i < k - i) acc += (uint64_t)a.v[i] * a2[k - i];
+        if (i == k - i) acc += (uint64_t)a.v[i] * a.v[i];
+      }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i)
+        if (!(k < L && i == k)) acc += (uint64_t)m[i] * PL.v[k - i];
+      if (k < L) {
+        m[k] = ((uint32_t)acc * N0) & MASK;
+        acc += (uint64_t)m[k] * PL.v[0];
+      } else {
+        r.v[k - L] = (uint32_t)acc & MASK;
+      }
+      acc >>= B;
+    }
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+  }
+
+  static FF_HD fe29 add(const fe29& a, const fe29& b) {
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = a.v[i] + b.v[i];
+    return r;
+  }
+  // a - b + MULT*p, limb by limb (no carries): kform<MULT,LIFT> must cover the limb bounds of b
+  template <uint32_t MULT, uint32_t LIFT>
+  static FF_HD fe29 subk(const fe29& a, const fe29& b) {
+    constexpr Limbs k = kform<MULT, LIFT>();
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = a.v[i] + k.v[i] - b.v[i];
+    return r;
+  }
+  // a - b - 2c + MULT*p
+  template <uint32_t MULT, uint32_t LIFT>
+  static FF_HD fe29 subk2(const fe29& a, const fe29& b, const fe29& c) {
+    constexpr Limbs k = kform<MULT, LIFT>();
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = a.v[i] + k.v[i] - b.v[i] - 2 * c.v[i];
+    return r;
+  }
+  template <uint32_t MULT, uint32_t LIFT>
+  static FF_HD fe29 negk(const fe29& b) {
+    constexpr Limbs k = kform<MULT, LIFT>();
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = k.v[i] - b.v[i];
+    return r;
+  }
+  // carry propagation: limbs 0..7 < 2^29 afterwards, same value
+  static FF_HD fe29 norm(const fe29& a) {
+    fe29 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+      uint32_t t = a.v[i] + c;
+      r.v[i] = t & MASK;
+      c = t >> B;
+    }
+    r.v[L - 1] = a.v[L - 1] + c;
+    return r;
+  }
+  // unique representative in [0, p) of a normalized value < 2*MAXMULT*p (MAXMULT a power of two)
+  template <uint32_t MAXMULT>
+  static FF_HD fe29 canon(fe29 a) {
+    if constexpr (MAXMULT > 1) a = canon_step<MAXMULT>(a);
+    if constexpr (MAXMULT > 1) return canon<MAXMULT / 2>(a);
+    return canon_step<1>(a);
+  }
+  template <uint32_t MULT>
+  static FF_HD fe29 canon_step(const fe29& a) {  // a >= MULT*p ? a - MULT*p : a
+    constexpr Limbs k = kform<MULT, 0>();
+    fe29 t;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+      int32_t d = (int32_t)a.v[i] - (int32_t)k.v[i] + borrow;
+      t.v[i] = (uint32_t)d & MASK;
+      borrow = d >> B;
+    }
+    int32_t top = (int32_t)a.v[L - 1] - (int32_t)k.v[L - 1] + borrow;
+    t.v[L - 1] = (uint32_t)top;
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = top < 0 ? a.v[i] : t.v[i];
+    return r;
+  }
+  // cheap necessary condition for a == 0 mod p of a normalized value < 32p: a = j*p forces a_0*p^-1 = j < 32
+  // (mod 2^29); false positives with probability 2^-24
+  static FF_HD bool maybe_zero(const fe29& a) { return ((a.v[0] * PINV0) & MASK) < 32u; }
+  template <uint32_t MAXMULT>
+  static FF_HD bool is_zero_exact(const fe29& a) {
+    return limbs_zero(canon<MAXMULT>(a));
+  }
+
+  // ---- layout conversion with ff.cuh (8 x 32-bit limbs) ----
+  static FF_HD fe29 relimb(const u256& x) {
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const int bit = B * i, w = bit >> 5, sh = bit & 31;
+      uint64_t two = (uint64_t)x.v[w] | (w + 1 < 8 ? (uint64_t)x.v[w + 1] << 32 : 0);
+      r.v[i] = (uint32_t)(two >> sh) & MASK;
+    }
+    return r;
+  }
+  static FF_HD u256 relimb(const fe29& a) {  // a canonical
+    u256 x;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const int bit = 32 * w, i = bit / B, sh = bit - B * i;
+      uint64_t t = (uint64_t)a.v[i] >> sh;
+      t |= (uint64_t)a.v[i + 1] << (B - sh);
+      if (i + 2 < L && 2 * B - sh < 32) t |= (uint64_t)a.v[i + 2] << (2 * B - sh);
+      x.v[w] = (uint32_t)t;
+    }
+    return x;
+  }
+  // Montgomery form of ff.cuh (x*2^256 mod p, canonical)  <->  canonical x*2^261 mod p
+  static FF_HD fe29 from_std(const u256& x) { return canon<1>(mul(relimb(x), constant(C_IN))); }
+  // any normalized value < 13p
+  static FF_HD u256 to_std(const fe29& a) { return relimb(canon<1>(mul(a, constant(C_OUT)))); }
+};
+
+}  // namespace g16

@@ -52,6 +52,7 @@ struct g16_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   Buf stage_s;   // staged scalars (host-pointer API)
   Buf stage_p;   // staged points
+  Buf stage_p29; // the same points as reduced-radix entries (one-shot MSMs; registered sets keep their own tables)
   Buf stage_o;   // result slot
   Buf ntt_tw;    // twiddle table
   Buf ntt_tmp;   // ping-pong buffers
@@ -154,6 +155,8 @@ int g16_stream_priority(int index);
                              void* wsum, void* out_aff, void* out_acc);
 G16_DECL_STAGES(g1)
 G16_DECL_STAGES(g2)
+int32_t g16_to29_device_g1(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out);
+int32_t g16_to29_device_g2(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out);
 int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
 uint32_t g16_pick_window_g1(size_t n);

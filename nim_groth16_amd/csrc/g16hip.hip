@@ -74,7 +74,7 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
     if (srt.buf.p) (void)hipFree(srt.buf.p);
   if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
-  for (g16_ctx::Buf* b : {&ctx->stage_s, &ctx->stage_p, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
+  for (g16_ctx::Buf* b : {&ctx->stage_s, &ctx->stage_p, &ctx->stage_p29, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
                           &ctx->coset[0], &ctx->coset[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
                           &ctx->fb_table[1]})
     if (b->p) (void)hipFree(b->p);
@@ -218,7 +218,7 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
     return G16_EINVAL;
   }
   if (n) {
-    hipError_t e = hipMalloc(&h->d_tables, (size_t)h->nwin * n * psz);
+    hipError_t e = hipMalloc(&h->d_tables, (size_t)h->nwin * n * (psz + psz / 8));   // 72 / 144-byte reduced-radix entries
     if (e != hipSuccess) {
       delete h;
       ctx->err = "hipMalloc(tables) failed";

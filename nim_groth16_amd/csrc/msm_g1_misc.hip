@@ -1,5 +1,8 @@
 // G1 registration-time tables, fixed-base multiples of gen1, on-curve check
 #include "msm_stage.cuh"
+int32_t g16_to29_device_g1(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out) {
+  return to29_device<G1>(ctx, st, d_points, n, d_out);
+}
 int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
   return precompute_device<G1>(ctx, d_points, n, c, d_tables);
 }

@@ -5,6 +5,9 @@ static u256 std_fp(uint32_t a7, uint32_t a6, uint32_t a5, uint32_t a4, uint32_t 
   v.v[0] = a0; v.v[1] = a1; v.v[2] = a2; v.v[3] = a3; v.v[4] = a4; v.v[5] = a5; v.v[6] = a6; v.v[7] = a7;
   return Fp::to_mont(v);   // standard form -> Montgomery
 }
+int32_t g16_to29_device_g2(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out) {
+  return to29_device<G2>(ctx, st, d_points, n, d_out);
+}
 int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
   return precompute_device<G2>(ctx, d_points, n, c, d_tables);
 }

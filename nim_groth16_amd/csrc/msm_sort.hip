@@ -52,6 +52,14 @@ static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32
                           void* d_out_aff, void* d_out_acc, uint32_t table_c) {
   int32_t rc = msm_sort_device(ctx, ctx->stream, d_scalars, flags, n, table_c, ctx->sort[0]);
   if (rc) return rc;
+  if (table_c == 0 && n) {   // plain point array: the accumulate kernel reads reduced-radix entries
+    const size_t esz = group == 1 ? 72 : 144;
+    if ((rc = ensure(ctx, ctx->stage_p29, n * esz))) return rc;
+    rc = group == 1 ? g16_to29_device_g1(ctx, ctx->stream, d_points, n, ctx->stage_p29.p)
+                    : g16_to29_device_g2(ctx, ctx->stream, d_points, n, ctx->stage_p29.p);
+    if (rc) return rc;
+    d_points = ctx->stage_p29.p;
+  }
   return msm_reduce(ctx, ctx->stream, ctx->lane[0].acc, ctx->sort[0], group, d_points, d_out_aff, d_out_acc);
 }
 int32_t g16_msm_device_g1(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* aff, void* acc,

@@ -1,11 +1,25 @@
 // Test-only: compiles the *device* field/curve headers with g++ so their formulas can be checked
 // against the oracle on a machine without a GPU.  Not part of the product library.
-#include "../../nim_groth16_amd/csrc/ec.cuh"
+#include "../../nim_groth16_amd/csrc/ec29.cuh"
 #include <cstring>
 using namespace g16;
 
 template <class T> static T ld(const void* p) { T t; std::memcpy(&t, p, sizeof(T)); return t; }
 template <class T> static void st(void* p, const T& t) { std::memcpy(p, &t, sizeof(T)); }
+
+// the reduced-radix accumulate path (ec29.cuh): op 0: acc += q_i ; op 1: acc += -(-q_i) through the sign flag
+template <class C>
+static void sum29(int op, const void* pts, int n, void* out) {
+  using E = Ec29<C>;
+  typename E::Acc acc = E::acc_inf();
+  const char* p = (const char*)pts;
+  for (int i = 0; i < n; ++i) {
+    typename C::Aff q = ld<typename C::Aff>(p + sizeof(typename C::Aff) * i);
+    if (op == 1) q = C::neg(q);
+    E::madd(acc, E::from_std(q), op == 1 ? 1u : 0u);
+  }
+  st(out, C::to_affine(E::to_std(acc)));
+}
 
 extern "C" {
 // op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 dbl 6 div2 7 inv 8 from_mont 9 to_mont ; field: 0 Fp 1 Fr
@@ -56,6 +70,20 @@ void shim_g1_sum(int op, const void* pts, int n, void* out) {
     }
   }
   st(out, G1::to_affine(acc));
+}
+void shim_g1_sum29(int op, const void* pts, int n, void* out) { sum29<G1>(op, pts, n, out); }
+void shim_g2_sum29(int op, const void* pts, int n, void* out) { sum29<G2>(op, pts, n, out); }
+// op 0: to_std(mul(from_std a, from_std b))  1: to_std(sqr(from_std a))  2: to_std(from_std a)
+// 3: to_std(dot2(a,b,a,b)) = 2ab
+void shim_f29_op(int op, const void* a, const void* b, void* r) {
+  fe29 x = Fp29::from_std(ld<u256>(a)), y = Fp29::from_std(ld<u256>(b)), z;
+  switch (op) {
+    case 0: z = Fp29::mul(x, y); break;
+    case 1: z = Fp29::sqr(x); break;
+    case 2: z = x; break;
+    default: z = Fp29::dot2(x, y, x, y); break;
+  }
+  st(r, Fp29::to_std(z));
 }
 void shim_g2_sum(int op, const void* pts, int n, void* out) {
   g2_acc acc = G2::acc_inf();

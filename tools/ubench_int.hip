@@ -15,7 +15,7 @@ constexpr int CHAINS = 8;
 constexpr int UNROLL = 4;   // x CHAINS instructions per loop iteration
 
 enum Op { ADD_U32, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24,
-          FMA_F64, ADDC_PAIR, FMA_F32, MAD_U32_U16, LSHL_ADD_U64, MUL_U32_U24, MAD_U64_DEP };
+          FMA_F64, ADDC_PAIR, FMA_F32, MAD_U32_U16, LSHL_ADD_U64, MUL_U32_U24, MAD_U64_DEP, LSHR_B64, ALIGNBIT, AND_B32, MAD_U64_SGPR, ADD3_U32, LSHL_OR };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed) {
@@ -60,6 +60,18 @@ __global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed
           asm volatile("v_mad_u32_u16 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
         else if constexpr (OP == LSHL_ADD_U64)
           asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS]));
+        else if constexpr (OP == LSHR_B64)
+          asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(w[i]));
+        else if constexpr (OP == ALIGNBIT)
+          asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == AND_B32)
+          asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == ADD3_U32)
+          asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == LSHL_OR)
+          asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b[i]));
+        else if constexpr (OP == MAD_U64_SGPR)
+          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "s"(seed) : "vcc");
         else if constexpr (OP == MAD_U64_DEP)   // single dependent chain through chain 0
           asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[0]) : "v"(a[i]), "v"(b[i]) : "vcc");
       }
@@ -112,6 +124,12 @@ int main() {
     run<FMA_F64>("v_fma_f64", blocks, iters, out);
     run<ADDC_PAIR>("add_co+addc", blocks, iters, out, 2);
     run<LSHL_ADD_U64>("v_lshl_add_u64", blocks, iters, out);
+    run<LSHR_B64>("v_lshrrev_b64", blocks, iters, out);
+    run<ALIGNBIT>("v_alignbit_b32", blocks, iters, out);
+    run<AND_B32>("v_and_b32", blocks, iters, out);
+    run<ADD3_U32>("v_add3_u32", blocks, iters, out);
+    run<LSHL_OR>("v_lshl_or_b32", blocks, iters, out);
+    run<MAD_U64_SGPR>("v_mad_u64 sgpr", blocks, iters, out);
   }
   return 0;
 }
