@@ -186,6 +186,37 @@ int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* key, const void* partial
 /* buildABC alone (prover.nim:56-73): out_abc = Az | Bz | Cz, 3 * domainSize Fr (Montgomery), host memory */
 int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, void* out_abc);
 
+/* ---- verifier ------------------------------------------------------------------------
+ * Replaces verifyProof (groth16/verifier.nim:31-52), extractVKey / VKey (groth16/zkey_types.nim:62-73) and the
+ * `pairing` of bn128/curves.nim:218-221, on the device, batched over proofs.
+ *
+ * g16_vkey_desc: npubs = number of public inputs; pointsIC holds npubs + 1 G1 points (the first one belongs to
+ * the constant 1).  alpha1: 64 B; beta2, gamma2, delta2: 128 B each (Montgomery affine, as everywhere).
+ * g16_verify: `public_io` = count x (npubs + 1) scalars, each row starting with the constant 1 exactly like
+ * Proof.publicIO (prover.nim:238-240); flags: G16_SCALARS_MONT / G16_SCALARS_STD for the scalars, and
+ * G16_VERIFY_SUBGROUP to also require [r]pi_b = infinity (the reference only asserts the curve equations).
+ * status[j]: 1 = proof j verifies, 0 = pairing equation fails, -1 / -2 / -3 = pi_a / pi_b / pi_c is not on its
+ * curve (the reference's three asserts), -4 = pi_b is not in the order-r subgroup.
+ * g16_pairing: out_gt[i] = e(P_i, Q_i) as 6 x Fp2 = 384 bytes, coefficient k of w^k in
+ * Fp12 = Fp2[w]/(w^6 - (9+u)) (the tower of files/export_sage.nim:84-97 flattened), Montgomery form;
+ * e is the ate pairing f_{t-1,Q}(P)^((p^12-1)/r). */
+typedef struct g16_vkey g16_vkey;
+typedef struct {
+  uint32_t npubs;
+  const void* alpha1;
+  const void* beta2;
+  const void* gamma2;
+  const void* delta2;
+  const void* pointsIC;
+} g16_vkey_desc;
+#define G16_VERIFY_SUBGROUP 16u
+#define G16_GT_BYTES 384
+int32_t g16_vkey_create(g16_ctx* ctx, const g16_vkey_desc* desc, g16_vkey** out);
+void g16_vkey_destroy(g16_vkey* key);
+int32_t g16_verify(g16_ctx* ctx, const g16_vkey* key, const g16_proof* proofs, const void* public_io, uint32_t flags,
+                   size_t count, int32_t* status);
+int32_t g16_pairing(g16_ctx* ctx, const void* g1_points, const void* g2_points, size_t n, void* out_gt);
+
 /* ---- profiling ---------------------------------------------------------------------------------- */
 /* when enabled, every kernel launch is bracketed by HIP events on the context's stream */
 int32_t g16_profile_enable(g16_ctx* ctx, int32_t on);

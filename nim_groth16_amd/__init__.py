@@ -5,9 +5,10 @@ groth16/bn128/msm.nim, groth16/math/ntt.nim, groth16/math/domain.nim) over the C
 libg16hip.so (include/g16hip.h).  All arithmetic runs in hand-written HIP kernels; there is no CPU
 fallback -- importing works anywhere, but every compute call raises without the HIP library + a GPU.
 """
-from ._lib import G16Error, Context, ProvingKey, PointSet, lib_path, load_library  # noqa: F401
+from ._lib import G16Error, Context, ProvingKey, PointSet, VerifyingKey, lib_path, load_library  # noqa: F401
 from .msm import (msmMultiThreadedG1, msmMultiThreadedG2, msmG1, msmG2)  # noqa: F401
 from .ntt import Domain, createDomain, forwardNTT, inverseNTT  # noqa: F401
 from .prover import (Proof, Mask, Witness, generateProof, generateProofWithMask,  # noqa: F401
                      generateProofWithTrivialMask, loadProvingKey)
+from .verifier import VKey, extractVKey, loadVerifyingKey, verifyProof, verifyProofs  # noqa: F401
 from .zkey_types import ZKey, GrothHeader, SpecPoints, ProverPoints, JensGroth, Snarkjs  # noqa: F401

@@ -22,7 +22,10 @@ SYMBOLS = [
     "g16_points_check_g1", "g16_points_check_g2", "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
     "g16_pkey_destroy", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
+    "g16_vkey_create", "g16_vkey_destroy", "g16_verify", "g16_pairing",
 ]
+VERIFY_SUBGROUP = 16
+GT_BYTES = 384
 
 
 class PkeyDesc(ctypes.Structure):
@@ -35,6 +38,12 @@ class PkeyDesc(ctypes.Structure):
                 ("alpha1", ctypes.c_void_p), ("beta1", ctypes.c_void_p), ("delta1", ctypes.c_void_p),
                 ("beta2", ctypes.c_void_p), ("delta2", ctypes.c_void_p),
                 ("shard_index", ctypes.c_uint32), ("shard_count", ctypes.c_uint32)]
+
+
+class VkeyDesc(ctypes.Structure):
+    """g16_vkey_desc (include/g16hip.h)"""
+    _fields_ = [("npubs", ctypes.c_uint32), ("alpha1", ctypes.c_void_p), ("beta2", ctypes.c_void_p),
+                ("gamma2", ctypes.c_void_p), ("delta2", ctypes.c_void_p), ("pointsIC", ctypes.c_void_p)]
 
 
 class G16Error(RuntimeError):
@@ -104,12 +113,17 @@ def load_library():
     lib.g16_prove_combine.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp]
     lib.g16_ntt_fr.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_ntt_fr_dev.argtypes = [vp, vp, vp, u32, i32]
+    lib.g16_vkey_create.argtypes = [vp, ctypes.POINTER(VkeyDesc), ctypes.POINTER(vp)]
+    lib.g16_vkey_destroy.argtypes = [vp]
+    lib.g16_vkey_destroy.restype = None
+    lib.g16_verify.argtypes = [vp, vp, vp, vp, u32, sz, ctypes.POINTER(i32)]
+    lib.g16_pairing.argtypes = [vp, vp, vp, sz, vp]
     lib.g16_profile_enable.argtypes = [vp, i32]
     lib.g16_profile_reset.argtypes = [vp]
     lib.g16_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
     for name in SYMBOLS:
         if name not in ("g16_ctx_destroy", "g16_last_error", "g16_points_release", "g16_points_count",
-                        "g16_pkey_destroy"):
+                        "g16_pkey_destroy", "g16_vkey_destroy"):
             getattr(lib, name).restype = i32
     _lib = lib
     return lib
@@ -242,6 +256,15 @@ class Context:
         return out.raw
 
     # ---- profiling -----------------------------------------------------------------------------
+    def pairing(self, g1_points: bytes, g2_points: bytes) -> bytes:
+        """e(P_i, Q_i) for n pairs -> n x 384 bytes (6 x Fp2 over w^k, Montgomery; curves.nim:218-221)"""
+        n = len(g1_points) // 64
+        assert len(g1_points) == 64 * n and len(g2_points) == 128 * n
+        out = ctypes.create_string_buffer(max(1, GT_BYTES * n))
+        self._check(self._lib.g16_pairing(self._h, _buf(g1_points) if n else None, _buf(g2_points) if n else None,
+                                          n, out))
+        return out.raw[:GT_BYTES * n]
+
     def profile(self, on: bool):
         self._check(self._lib.g16_profile_enable(self._h, 1 if on else 0))
 
@@ -305,6 +328,50 @@ class ProvingKey:
     def _free(self):
         if self._h and self.ctx._h:
             self.ctx._lib.g16_pkey_destroy(self._h)
+        self._h = None
+
+    destroy = _free
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+class VerifyingKey:
+    """Device-resident verification key (g16_vkey): IC points, gamma2, delta2 and the Miller value of
+    (alpha1, beta2) -- the reference's VKey (zkey_types.nim:62-73)."""
+
+    def __init__(self, ctx: Context, npubs: int, alpha1: bytes, beta2: bytes, gamma2: bytes, delta2: bytes,
+                 pointsIC: bytes):
+        assert len(alpha1) == 64 and len(beta2) == len(gamma2) == len(delta2) == 128
+        assert len(pointsIC) == 64 * (npubs + 1), "pointsIC must hold npubs + 1 points"
+        self.ctx, self.npubs = ctx, npubs
+        bufs = [ctypes.create_string_buffer(x, len(x)) for x in (alpha1, beta2, gamma2, delta2, pointsIC)]
+        a = [ctypes.cast(b, ctypes.c_void_p) for b in bufs]
+        desc = VkeyDesc(npubs, a[0], a[1], a[2], a[3], a[4])
+        h = ctypes.c_void_p()
+        ctx._check(ctx._lib.g16_vkey_create(ctx._h, ctypes.byref(desc), ctypes.byref(h)))
+        self._h = h
+        ctx._children.add(self)
+
+    def verify(self, proofs, public_io: bytes, mont: bool = True, subgroup: bool = False):
+        """proofs: list of (pi_a, pi_b, pi_c) byte triples; public_io: len(proofs) x (npubs+1) Fr scalars (each row
+        starts with the constant 1, like Proof.publicIO).  -> list of status codes (1 ok, 0 fails, <0 malformed)."""
+        n = len(proofs)
+        assert len(public_io) == 32 * n * (self.npubs + 1)
+        raw = b"".join(a + b + c for a, b, c in proofs)
+        assert len(raw) == 256 * n
+        st = (ctypes.c_int32 * max(n, 1))()
+        flags = (SCALARS_MONT if mont else 0) | (VERIFY_SUBGROUP if subgroup else 0)
+        self.ctx._check(self.ctx._lib.g16_verify(self.ctx._h, self._h, _buf(raw) if n else None,
+                                                 _buf(public_io) if n else None, flags, n, st))
+        return list(st)[:n]
+
+    def _free(self):
+        if self._h and self.ctx._h:
+            self.ctx._lib.g16_vkey_destroy(self._h)
         self._h = None
 
     destroy = _free

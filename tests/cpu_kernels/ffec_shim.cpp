@@ -1,6 +1,7 @@
 // Test-only: compiles the *device* field/curve headers with g++ so their formulas can be checked
 // against the oracle on a machine without a GPU.  Not part of the product library.
 #include "../../nim_groth16_amd/csrc/ec29.cuh"
+#include "../../nim_groth16_amd/csrc/pairing.cuh"
 #include <cstring>
 using namespace g16;
 
@@ -97,5 +98,17 @@ void shim_g2_sum(int op, const void* pts, int n, void* out) {
     }
   }
   st(out, G2::to_affine(acc));
+}
+// op 0: Miller loop f_{6x^2,Q}(P)   1: full pairing   2: final exponentiation of the Fp12 element at `p`
+// out: 6 x Fp2 (384 bytes, Montgomery form), coefficient k belongs to w^k
+void shim_pairing(int op, const void* p, const void* q, void* out) {
+  fp12_t f;
+  if (op == 2) {
+    Pairing::final_exp(f, ld<fp12_t>(p));
+  } else {
+    Pairing::miller(f, ld<g1_aff>(p), ld<g2_aff>(q));
+    if (op == 1) { fp12_t t = f; Pairing::final_exp(f, t); }
+  }
+  st(out, f);
 }
 }

@@ -137,3 +137,36 @@ def test_reduced_radix_interval_model():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     m.main()
+
+
+def _gt_from_bytes(raw):
+    """384-byte flat Fp12 (6 x Fp2 over w^k, Montgomery) -> the oracle's degree-12 polynomial basis"""
+    out = [0] * 12
+    for k in range(6):
+        a = o.fp_from_mont_bytes(raw[64 * k:64 * k + 32])
+        b = o.fp_from_mont_bytes(raw[64 * k + 32:64 * k + 64])
+        e = o._emb((a, b), k)
+        out = [(x + y) % o.P for x, y in zip(out, e)]
+    return out
+
+
+def test_pairing_formulas(shim):
+    """pairing.cuh (Miller loop + exact final exponentiation) against the oracle's ate pairing, bit for bit"""
+    rng = random.Random(21)
+    buf = ctypes.create_string_buffer(384)
+    for trial in range(2):
+        a, b = rng.randrange(1, o.R), rng.randrange(1, o.R)
+        Pt, Q = o.G1.mul(a, o.GEN1), o.G2.mul(b, o.GEN2)
+        shim.shim_pairing(0, o.g1_to_bytes(Pt), o.g2_to_bytes(Q), buf)
+        f = o.miller_loop(Pt, Q)
+        assert _gt_from_bytes(buf.raw) == f
+        shim.shim_pairing(1, o.g1_to_bytes(Pt), o.g2_to_bytes(Q), buf)
+        assert _gt_from_bytes(buf.raw) == o.final_exp(f)
+    # bilinearity through the product path alone: e(aP, bQ) == e(abP, Q)
+    shim.shim_pairing(1, o.g1_to_bytes(o.G1.mul(a * b % o.R, o.GEN1)), o.g2_to_bytes(o.GEN2), buf)
+    e1 = buf.raw
+    shim.shim_pairing(1, o.g1_to_bytes(o.G1.mul(a, o.GEN1)), o.g2_to_bytes(o.G2.mul(b, o.GEN2)), buf)
+    assert buf.raw == e1
+    # infinity on either side -> 1
+    shim.shim_pairing(1, o.g1_to_bytes(o.INF_G1), o.g2_to_bytes(o.GEN2), buf)
+    assert _gt_from_bytes(buf.raw) == o._f12_one()
