@@ -250,7 +250,12 @@ def main():
             raise SystemExit("FAIL: GPU proof differs from the CPU oracle's proof")
         if not o.verify_proof(oz, ref):
             raise SystemExit("FAIL: proof does not satisfy the pairing equation")
-        log(f"[bench] correctness gate passed: GPU proof == CPU oracle proof (bit-exact), pairing check ok")
+        from nim_groth16_amd import Proof, extractVKey, verifyProof
+        pio = wbytes[:32 * (hdr.npubs + 1)]      # Proof.publicIO = witness[0..npubs] (prover.nim:238-240)
+        if not verifyProof(extractVKey(zkey), Proof(pio, proof[0], proof[1], proof[2]), ctx):
+            raise SystemExit("FAIL: the GPU verifier rejects the proof")
+        log(f"[bench] correctness gate passed: GPU proof == CPU oracle proof (bit-exact), pairing check ok "
+            f"(oracle and GPU verifier)")
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
             cpu = {"value": round(1.0 / cpu_s, 5), "unit": "proofs/s", "cores": orc.cores(), "kind": "port",
                    "sample": f"1 full proof (buildABC + 6 NTT + 4 G1 MSM + 1 G2 MSM), domain 2^{args.log2n}, "

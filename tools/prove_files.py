@@ -23,6 +23,8 @@ def main():
     ap.add_argument("-i", "--io", default="public.json")
     ap.add_argument("-n", "--nomask", action="store_true", help="trivial mask r = s = 0 (cli_main.nim -n)")
     ap.add_argument("-t", "--time", action="store_true")
+    ap.add_argument("-y", "--verify", action="store_true",
+                    help="also verify the proof against the zkey's verification key (cli_main.nim -y)")
     args = ap.parse_args()
     ctx = Context(0)
     ctx.selftest()
@@ -36,6 +38,12 @@ def main():
     t3 = time.time()
     exportProof(args.output, proof)
     exportPublicIO(args.io, proof)
+    if args.verify:
+        from nim_groth16_amd import extractVKey, verifyProof
+        ok = verifyProof(extractVKey(zkey), proof, ctx)
+        print("verification " + ("succeeded" if ok else "FAILED"))
+        if not ok:
+            raise SystemExit(1)
     if args.time:
         print(f"parsing {t1-t0:.3f}s | key upload + tables {t2-t1:.3f}s | proof {t3-t2:.3f}s")
 
