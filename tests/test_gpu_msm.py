@@ -123,6 +123,28 @@ def test_msm_registered_points_tables(ctx, orc, group, n):
         h.release()
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_registered_repeated_and_opposite_points(ctx, orc, group):
+    """snarkjs keys repeat points; with equal scalars they meet in ONE bucket of the merged bucket set, where the
+    reduced-radix accumulate must take its exact P+P (doubling) and P-P (infinity) paths (ec29.cuh)."""
+    psz = PSZ[group]
+    _, pts = I.points_with_logs(orc, group, 4, seed=81)
+    P = [pts[psz * i:psz * (i + 1)] for i in range(4)]
+    C = o.G1 if group == 1 else o.G2
+    dec, enc = (o.g1_from_bytes, o.g1_to_bytes) if group == 1 else (o.g2_from_bytes, o.g2_to_bytes)
+    neg0 = enc(C.neg(dec(P[0])))
+    pl = [P[0]] * 5 + [neg0] * 2 + [P[1], P[1], INF[group], P[2], neg0, P[0]] + [P[3]] * 3
+    rng = o.SplitMix64(82)
+    k = rng.fr()
+    for sc in ([k] * len(pl), [3] * len(pl), [k] * 7 + [rng.fr() for _ in range(len(pl) - 7)]):
+        sb, pb = I.fr_mont_bytes(sc), b"".join(pl)
+        h = ctx.register_points(group, pb, len(pl))
+        try:
+            assert ctx.msm_points(h, sb) == orc.msm_naive(group, sb, pb)
+        finally:
+            h.release()
+
+
 def test_msm_registered_empty(ctx):
     h = ctx.register_points(1, b"", 0)
     assert ctx.msm_points(h, b"") == INF[1]
