@@ -267,7 +267,7 @@ def main():
                       f"proofs/sec (BN254 Groth16, 2^{args.log2n} domain)",
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 (8-limb 254-bit Montgomery)",
+            "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 (254-bit Montgomery: 8x32-bit limbs; 9x29-bit limbs in the bucket accumulation)",
             "data": "synthetic",
             "config": {"workload": f"BN254 2^{args.log2n}-constraint synthetic R1CS (squaring chain, m=2^{args.log2n}-2), "
                                    "full prove: buildABC + 6 NTT + 4 G1 MSM + 1 G2 MSM, snarkjs flavour, 1 proof/step/GPU"

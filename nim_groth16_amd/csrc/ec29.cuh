@@ -27,7 +27,17 @@ struct alignas(16) g2_aff29 {
 struct g2_acc29 {
   f2e29 x, y, zz, zzz;
 };
-static_assert(sizeof(g1_aff29) == 72 && sizeof(g2_aff29) == 144, "reduced-radix table entry sizes");
+// Table entries in HBM: the same canonical integers x*2^261 mod p, packed as plain 256-bit little-endian words
+// (64 B per G1 point, 128 B per G2 point): one aligned 64 / 128-byte gather per bucket entry.  (Stored as 9
+// 32-bit limbs an entry is 72 / 144 B and straddles sectors: rocprofv3 FETCH_SIZE showed 1.96 GB per 2^20 G1
+// launch, 2x the bytes asked for.)  Unpacking is bit slicing: ~2 VALU instructions per limb.
+struct alignas(16) g1_tab29 {
+  u256 x, y;
+};
+struct alignas(16) g2_tab29 {
+  u256 x0, x1, y0, y1;
+};
+static_assert(sizeof(g1_tab29) == 64 && sizeof(g2_tab29) == 128, "packed table entry sizes");
 
 template <class C>
 struct Ec29;
@@ -39,7 +49,11 @@ struct Ec29<G1> {
   using Aff = g1_aff29;
   using Acc = g1_acc29;
 
+  using Tab = g1_tab29;
   static FF_HD Aff from_std(const g1_aff& p) { return Aff{F::from_std(p.x), F::from_std(p.y)}; }
+  static FF_HD Tab pack(const Aff& p) { return Tab{F::relimb(p.x), F::relimb(p.y)}; }   // p canonical
+  static FF_HD Aff unpack(const Tab& t) { return Aff{F::relimb(t.x), F::relimb(t.y)}; }
+  static FF_HD Tab tab_from_std(const g1_aff& p) { return pack(from_std(p)); }
   static FF_HD bool is_inf(const Aff& p) { return F::limbs_zero(p.x) && F::limbs_zero(p.y); }
   static FF_HD bool is_inf(const Acc& a) { return F::limbs_zero(a.zz); }
   static FF_HD Acc acc_inf() { return Acc{F::zero(), F::zero(), F::zero(), F::zero()}; }
@@ -53,29 +67,37 @@ struct Ec29<G1> {
   }
   // the exceptional cases of the addition (q == +-acc as group elements); by value: a by-reference call would
   // pin the accumulator to scratch memory
-  static FF_HD_COLD Acc exceptional(Aff q, uint32_t neg, bool same) {
+  static FF_HD_COLD Acc exceptional(const Tab* tp, uint32_t neg, bool same) {
     if (!same) return acc_inf();
+    const Aff q = unpack(*tp);   // re-read: keeping the entry live across the hot path would cost registers
     g1_aff s{F::to_std(q.x), F::to_std(q.y)};
     if (neg) s = G1::neg(s);
     return acc_from_std(G1::dbl_affine(s));
   }
 
-  // acc += (neg ? -q : q)
-  static FF_HD void madd(Acc& acc, const Aff& q, uint32_t neg) {
-    if (is_inf(q)) return;
-    fe29 qy = q.y;
-    if (neg) qy = F::norm(F::negk<2, 1>(q.y));
+  static FF_HD bool is_inf(const Tab& t) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= t.x.v[i] | t.y.v[i];
+    return o == 0;
+  }
+  // acc += (neg ? -q : q), q given as a packed table entry
+  static FF_HD void madd(Acc& acc, const Tab* tp, uint32_t neg) {
+    const Tab t = *tp;
+    if (is_inf(t)) return;
+    fe29 qx = F::relimb(t.x), qy = F::relimb(t.y);
+    if (neg) qy = F::norm(F::negk<2, 1>(qy));
     if (is_inf(acc)) {
-      acc = Acc{q.x, qy, F::one(), F::one()};
+      acc = Acc{qx, qy, F::one(), F::one()};
       return;
     }
-    fe29 u2 = F::mul(q.x, acc.zz);
+    fe29 u2 = F::mul(qx, acc.zz);
     fe29 s2 = F::mul(qy, acc.zzz);
     fe29 nP = F::norm(F::subk<16, 1>(u2, acc.x));
     fe29 nR = F::norm(F::subk<4, 1>(s2, acc.y));
     if (F::maybe_zero(nP)) {
       if (F::is_zero_exact<16>(nP)) {
-        acc = exceptional(q, neg, F::is_zero_exact<4>(nR));
+        acc = exceptional(tp, neg, F::is_zero_exact<4>(nR));
         return;
       }
     }
@@ -121,7 +143,15 @@ struct Ec29<G2> {
     return f2e29{F::mul(s, d), F::mul(F::add(a.c0, a.c0), a.c1)};
   }
 
+  using Tab = g2_tab29;
   static FF_HD Aff from_std(const g2_aff& p) { return Aff{f2_from_std(p.x), f2_from_std(p.y)}; }
+  static FF_HD Tab pack(const Aff& p) {   // p canonical
+    return Tab{F::relimb(p.x.c0), F::relimb(p.x.c1), F::relimb(p.y.c0), F::relimb(p.y.c1)};
+  }
+  static FF_HD Aff unpack(const Tab& t) {
+    return Aff{f2e29{F::relimb(t.x0), F::relimb(t.x1)}, f2e29{F::relimb(t.y0), F::relimb(t.y1)}};
+  }
+  static FF_HD Tab tab_from_std(const g2_aff& p) { return pack(from_std(p)); }
   static FF_HD bool is_inf(const Aff& p) { return f2_limbs_zero(p.x) && f2_limbs_zero(p.y); }
   static FF_HD bool is_inf(const Acc& a) { return f2_limbs_zero(a.zz); }
   static FF_HD Acc acc_inf() { return Acc{f2_zero(), f2_zero(), f2_zero(), f2_zero()}; }
@@ -133,28 +163,40 @@ struct Ec29<G2> {
     if (G2::is_inf(a)) return acc_inf();
     return Acc{f2_from_std(a.x), f2_from_std(a.y), f2_from_std(a.zz), f2_from_std(a.zzz)};
   }
-  static FF_HD_COLD Acc exceptional(Aff q, uint32_t neg, bool same) {
+  static FF_HD_COLD Acc exceptional(const Tab* tp, uint32_t neg, bool same) {
     if (!same) return acc_inf();
+    const Aff q = unpack(*tp);
     g2_aff s{f2_to_std(q.x), f2_to_std(q.y)};
     if (neg) s = G2::neg(s);
     return acc_from_std(G2::dbl_affine(s));
   }
 
-  static FF_HD void madd(Acc& acc, const Aff& q, uint32_t neg) {
-    if (is_inf(q)) return;
-    f2e29 qy = q.y;
-    if (neg) qy = f2e29{F::norm(F::negk<2, 1>(q.y.c0)), F::norm(F::negk<2, 1>(q.y.c1))};
+  static FF_HD bool is_inf(const Tab& t) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= t.x0.v[i] | t.x1.v[i] | t.y0.v[i] | t.y1.v[i];
+    return o == 0;
+  }
+  // acc += (neg ? -q : q), q given as a packed table entry: each coordinate is unpacked where it is consumed
+  // (unpacking all 36 limbs up front costs registers the G2 kernel does not have)
+  static FF_HD void madd(Acc& acc, const Tab* tp, uint32_t neg) {
+    const Tab t = *tp;
+    if (is_inf(t)) return;
     if (is_inf(acc)) {
-      acc = Acc{q.x, qy, f2_one(), f2_one()};
+      Aff q = unpack(t);
+      if (neg) q.y = f2e29{F::norm(F::negk<2, 1>(q.y.c0)), F::norm(F::negk<2, 1>(q.y.c1))};
+      acc = Acc{q.x, q.y, f2_one(), f2_one()};
       return;
     }
-    f2e29 u2 = f2mul<4>(q.x, acc.zz);
+    f2e29 u2 = f2mul<4>(f2e29{F::relimb(t.x0), F::relimb(t.x1)}, acc.zz);
+    f2e29 qy{F::relimb(t.y0), F::relimb(t.y1)};
+    if (neg) qy = f2e29{F::norm(F::negk<2, 1>(qy.c0)), F::norm(F::negk<2, 1>(qy.c1))};
     f2e29 s2 = f2mul<4>(qy, acc.zzz);
     f2e29 nP{F::norm(F::subk<16, 1>(u2.c0, acc.x.c0)), F::norm(F::subk<16, 1>(u2.c1, acc.x.c1))};
     f2e29 nR{F::norm(F::subk<4, 1>(s2.c0, acc.y.c0)), F::norm(F::subk<4, 1>(s2.c1, acc.y.c1))};
     if (F::maybe_zero(nP.c0) && F::maybe_zero(nP.c1)) {
       if (F::is_zero_exact<16>(nP.c0) && F::is_zero_exact<16>(nP.c1)) {
-        acc = exceptional(q, neg, F::is_zero_exact<4>(nR.c0) && F::is_zero_exact<4>(nR.c1));
+        acc = exceptional(tp, neg, F::is_zero_exact<4>(nR.c0) && F::is_zero_exact<4>(nR.c1));
         return;
       }
     }

@@ -238,8 +238,14 @@ struct Fp29 {
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       const int bit = B * i, w = bit >> 5, sh = bit & 31;
+#if defined(__HIP_DEVICE_COMPILE__)
+      // one funnel shift per limb (v_alignbit_b32) instead of 64-bit shifts
+      uint32_t t = sh == 0 ? x.v[w] : (w + 1 < 8 ? __builtin_amdgcn_alignbit(x.v[w + 1], x.v[w], sh) : x.v[w] >> sh);
+      r.v[i] = t & MASK;
+#else
       uint64_t two = (uint64_t)x.v[w] | (w + 1 < 8 ? (uint64_t)x.v[w + 1] << 32 : 0);
       r.v[i] = (uint32_t)(two >> sh) & MASK;
+#endif
     }
     return r;
   }

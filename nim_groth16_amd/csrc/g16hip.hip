@@ -218,7 +218,7 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
     return G16_EINVAL;
   }
   if (n) {
-    hipError_t e = hipMalloc(&h->d_tables, (size_t)h->nwin * n * (psz + psz / 8));   // 72 / 144-byte reduced-radix entries
+    hipError_t e = hipMalloc(&h->d_tables, (size_t)h->nwin * n * psz);   // packed reduced-radix entries: 64 / 128 B
     if (e != hipSuccess) {
       delete h;
       ctx->err = "hipMalloc(tables) failed";

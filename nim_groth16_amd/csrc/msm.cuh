@@ -424,15 +424,16 @@ static __global__ void __launch_bounds__(PERM_BLOCK) perm_scatter(const uint32_t
 
 // ---- K4: bucket-segment accumulation -----------------------------------------------------------
 // The accumulate kernels work in the reduced-radix field of ff29.cuh (9 x 29-bit limbs: carry-free columns,
-// ~25 % fewer VALU cycles per multiplication than the 8 x 32 form).  They read point tables in that form
-// (72 B per G1 point, 144 B per G2 point; written by msm_precompute / points_to29) and write each bucket sum
-// back in the standard XYZZ layout, which is all the later stages ever see.
+// ~25 % fewer VALU cycles per multiplication than the 8 x 32 form).  They read point tables holding that
+// field's canonical values packed in 64 B per G1 point / 128 B per G2 point (written by msm_precompute /
+// points_to29, unpacked by bit slicing) and write each bucket sum back in the standard XYZZ layout, which is
+// all the later stages ever see.
 //
 // occupancy target: G1 fits 4 waves/SIMD (<=128 VGPRs); G2 is bounded to 256 registers (2 waves/SIMD;
 // 3 waves/SIMD with spills measured slower: 3.88 ms vs 3.52 ms on the 8x32 kernel)
 template <class C>
 __global__ void __launch_bounds__(MSM_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : G16_G2_WAVES)
-msm_accum(const typename Ec29<C>::Aff* __restrict__ points, const uint32_t* __restrict__ entries,
+msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __restrict__ entries,
           const uint32_t* __restrict__ offset, const uint2* __restrict__ xseg, const uint32_t* __restrict__ info,
           const uint32_t* __restrict__ perm, MsmParams P, typename C::Acc* __restrict__ partial) {
   using E = Ec29<C>;
@@ -458,7 +459,7 @@ msm_accum(const typename Ec29<C>::Aff* __restrict__ points, const uint32_t* __re
   typename E::Acc acc = E::acc_inf();
   for (uint32_t j = beg; j < end; ++j) {
     const uint32_t e = entries[j];   // point index (table-major) | sign in bit 31
-    E::madd(acc, points[e & 0x7fffffffu], e >> 31);
+    E::madd(acc, points + (e & 0x7fffffffu), e >> 31);
   }
   partial[slot] = E::to_std(acc);
 }
@@ -466,9 +467,9 @@ msm_accum(const typename Ec29<C>::Aff* __restrict__ points, const uint32_t* __re
 // affine points in the reference layout (64 / 128 B, Montgomery R = 2^256) -> reduced-radix table entries
 template <class C>
 __global__ void __launch_bounds__(MSM_BLOCK) points_to29(const typename C::Aff* __restrict__ points, uint32_t n,
-                                                         typename Ec29<C>::Aff* __restrict__ out) {
+                                                         typename Ec29<C>::Tab* __restrict__ out) {
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
-  if (i < n) out[i] = Ec29<C>::from_std(points[i]);
+  if (i < n) out[i] = Ec29<C>::tab_from_std(points[i]);
 }
 
 // ---- K5: combine the segments of split buckets (one workgroup per heavy bucket) ---------------------
@@ -658,15 +659,15 @@ __global__ void __launch_bounds__(64) msm_fold_merged(const typename C::Acc* __r
 template <class C>
 __global__ void __launch_bounds__(MSM_BLOCK) msm_precompute(const typename C::Aff* __restrict__ points, uint32_t n,
                                                             uint32_t c, uint32_t nwin,
-                                                            typename Ec29<C>::Aff* __restrict__ tables) {
+                                                            typename Ec29<C>::Tab* __restrict__ tables) {
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= n) return;
   typename C::Aff p = points[i];
-  tables[i] = Ec29<C>::from_std(p);
+  tables[i] = Ec29<C>::tab_from_std(p);
   typename C::Acc acc = C::from_affine(p);
   for (uint32_t w = 1; w < nwin; ++w) {
     for (uint32_t k = 0; k < c; ++k) acc = C::dbl(acc);
-    tables[(size_t)w * n + i] = Ec29<C>::from_std(C::to_affine(acc));
+    tables[(size_t)w * n + i] = Ec29<C>::tab_from_std(C::to_affine(acc));
   }
 }
 

@@ -53,7 +53,7 @@ static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32
   int32_t rc = msm_sort_device(ctx, ctx->stream, d_scalars, flags, n, table_c, ctx->sort[0]);
   if (rc) return rc;
   if (table_c == 0 && n) {   // plain point array: the accumulate kernel reads reduced-radix entries
-    const size_t esz = group == 1 ? 72 : 144;
+    const size_t esz = group == 1 ? 64 : 128;
     if ((rc = ensure(ctx, ctx->stage_p29, n * esz))) return rc;
     rc = group == 1 ? g16_to29_device_g1(ctx, ctx->stream, d_points, n, ctx->stage_p29.p)
                     : g16_to29_device_g2(ctx, ctx->stream, d_points, n, ctx->stage_p29.p);

@@ -13,7 +13,7 @@ static int32_t stage_accum(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort&
   const bool g2 = sizeof(typename C::Aff) == 128;
   const uint32_t ntask = P.nbuckets + P.max_extra;
   KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + MSM_BLOCK - 1) / MSM_BLOCK,
-             MSM_BLOCK, 0, (const typename Ec29<C>::Aff*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
+             MSM_BLOCK, 0, (const typename Ec29<C>::Tab*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
              (typename C::Acc*)partial);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
@@ -97,7 +97,7 @@ template <class C>
 static int32_t precompute_device(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
   const uint32_t nwin = FR_BITS / c + 1;
   KLAUNCH(ctx, "msm_precompute", msm_precompute<C>, (uint32_t)((n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0,
-          (const typename C::Aff*)d_points, (uint32_t)n, c, nwin, (typename Ec29<C>::Aff*)d_tables);
+          (const typename C::Aff*)d_points, (uint32_t)n, c, nwin, (typename Ec29<C>::Tab*)d_tables);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
@@ -107,7 +107,7 @@ template <class C>
 static int32_t to29_device(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out) {
   if (n)
     KLAUNCH_ON(ctx, st, "points_to29", points_to29<C>, (uint32_t)((n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0,
-               (const typename C::Aff*)d_points, (uint32_t)n, (typename Ec29<C>::Aff*)d_out);
+               (const typename C::Aff*)d_points, (uint32_t)n, (typename Ec29<C>::Tab*)d_out);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }

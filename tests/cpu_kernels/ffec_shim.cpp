@@ -17,7 +17,8 @@ static void sum29(int op, const void* pts, int n, void* out) {
   for (int i = 0; i < n; ++i) {
     typename C::Aff q = ld<typename C::Aff>(p + sizeof(typename C::Aff) * i);
     if (op == 1) q = C::neg(q);
-    E::madd(acc, E::from_std(q), op == 1 ? 1u : 0u);
+    const typename E::Tab t = E::tab_from_std(q);   // through the packed table entry
+    E::madd(acc, &t, op == 1 ? 1u : 0u);
   }
   st(out, C::to_affine(E::to_std(acc)));
 }

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Builds profiles/r01_pmc_hbm_traffic_2p20.json from two rocprofv3 counter passes of the bench command:
+
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc/fetch -o r01 -- \\
+      python3 bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc/write -o r01 -- (same command)
+  python3 tools/pmc_traffic.py gpurun_out/pmc profiles/r01_pmc_hbm_traffic_2p20.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch (summed over the XCDs here)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    base = re.split(r"[<(]", name.replace("void ", "").replace("g16::", "").replace("(anonymous namespace)::", ""))[0].strip()
+    if base.startswith("msm_") and ("Curve" in name or "Fp2" in name or "Field" in name):
+        base += "_g2" if "Fp2" in name else "_g1"
+    return base
+
+
+def load(path, counter):
+    per = collections.defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+        names[r["Dispatch_Id"]] = r["Kernel_Name"]
+    agg = collections.defaultdict(list)
+    for d, v in per.items():
+        agg[short(names[d])].append(v)
+    return agg
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    f = load(f"{root}/fetch/r01_counter_collection.csv", "FETCH_SIZE")
+    w = load(f"{root}/write/r01_counter_collection.csv", "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(f) | set(w)):
+        fa = sum(f[k]) / len(f[k]) if f.get(k) else 0.0
+        wa = sum(w[k]) / len(w[k]) if w.get(k) else 0.0
+        kernels[k] = {"FETCH_SIZE_KB_avg_per_launch": round(fa, 1), "WRITE_SIZE_KB_avg_per_launch": round(wa, 1),
+                      "launches": len(f.get(k) or w.get(k)), "hbm_bytes_per_launch_raw": int((fa + wa) * 1024)}
+    doc = {
+        "workload": "bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline (2^20 full prove), rocprofv3 --pmc "
+                    "FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
+        "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch; hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024",
+        "calibration": "ntt_pass moves a known 3 x 32 MiB in and out per launch (batched A/B/C): the counters read true "
+                       "bytes for this 32-byte-per-lane pattern (no x2 correction).  FETCH_SIZE = read requests x 64 B: "
+                       "msm_accum_g1 gathers one aligned 64-B table entry per bucket entry (13.6M x 64 B + 54 MB of "
+                       "entry indices = 0.93 GB asked for, 1.18 GB counted); msm_accum_g2 gathers aligned 128-B "
+                       "entries, which the counter tallies at 64 B each (MI355X_MICROARCH.md, HBM section), so its "
+                       "true fetch is about twice the raw figure (1.75 GB of entries).  History: 72/144-byte "
+                       "unpacked entries straddled sectors (1.96 GB counted for G1); a spilling G2 build wrote "
+                       "1.85 GB of scratch per launch (WRITE_SIZE) -- both fixed in step 12",
+        "kernels": kernels,
+    }
+    json.dump(doc, open(out, "w"), indent=1)
+    for k in ("msm_accum_g1", "msm_accum_g2", "ntt_pass"):
+        if k in kernels:
+            print(k, kernels[k])
+
+
+if __name__ == "__main__":
+    main()
