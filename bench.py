@@ -143,10 +143,17 @@ def main():
 
     run(max(args.warmup, inflight))
     barrier()
+    # HIP-event timing of the dominant kernels (bucket accumulation) runs INSIDE the timed region, on this rank's
+    # first context; events are recorded on the stream each kernel is launched on.  (Events around all ~130 launches
+    # of a proof cost ~3 % of throughput, so the full per-kernel breakdown is taken on extra steps afterwards.)
+    ctx.profile(2 if rank == 0 else 0)
+    ctx.profile_reset()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    rep = ctx.profile_report() if rank == 0 else {}
+    ctx.profile(False)
     proof = last[0]
     assert all(p == proof for p in last if p is not None), "in-flight lanes disagree"
     # single-proof latency (one proof in flight), reported next to the throughput
@@ -161,19 +168,20 @@ def main():
     proofs = args.steps * (1 if shard or world == 1 else world)
     value = proofs / dt
 
-    # ---- per-kernel HIP-event timing of the same step (roofline of the dominant kernel) ---------------------
+    # ---- roofline of the dominant kernel of the step (from the events of the timed region) -------------------
     roof, extra = None, {}
     reps = 3
     if rank == 0 or shard:            # in shard mode a step contains a collective: every rank must take part
-        ctx.profile(rank == 0)
+        ctx.profile(1 if rank == 0 else 0)
         ctx.profile_reset()
         for _ in range(reps):
             step()
-        rep = ctx.profile_report()
+        rep_all = ctx.profile_report() if rank == 0 else {}
         ctx.profile(False)
     if rank == 0:
         kern = {k: v["total_ms"] / v["calls"] for k, v in rep.items()}
-        calls = {k: v["calls"] // reps for k, v in rep.items()}
+        kern_all = {k: v["total_ms"] / v["calls"] for k, v in rep_all.items()}
+        calls = {k: v["calls"] // reps for k, v in rep_all.items()}
         dom = max(rep, key=lambda k: rep[k]["total_ms"])
         nsh = (n // world) if shard else n
         # algorithmic bytes of one launch: a G1 MSM reads 32+64 B per pair, a G2 MSM 32+128 B
@@ -194,7 +202,8 @@ def main():
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                 "avg_launch_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": alg,
                 "note": "MSM is integer-ALU-bound (254-bit Montgomery madds), not HBM-bound: see DESIGN.md"}
-        extra["kernel_ms_per_proof"] = {k: round(kern[k] * calls[k], 4) for k in sorted(kern)}
+        # all kernels of one proof (separate steps, one proof in flight, every launch bracketed by events)
+        extra["kernel_ms_per_proof"] = {k: round(kern_all[k] * calls[k], 4) for k in sorted(kern_all)}
         # G1-adds/sec: one stand-alone registered G1 MSM (witness x pointsA1), all phases, HIP-event timed
         nsh = n
         hA = ctx.register_points(1, zkey.pPoints.pointsA1, zkey.header.nvars)
@@ -212,6 +221,13 @@ def main():
         extra["msm_g1_adds_per_sec"] = round(adds / (g1 * 1e-3), 1)
         extra["msm_g1_pairs_per_sec"] = round(nsh / (g1 * 1e-3), 1)
         extra["msm_g1_ms"] = round(g1, 4)
+        if dom in rep1:     # the same kernel with the GPU to itself (no other lane / proof in flight)
+            iso = rep1[dom]["total_ms"] / rep1[dom]["calls"]
+            roof["isolated_launch_ms"] = round(iso, 4)
+            roof["achieved_isolated"] = round(alg / (iso * 1e-3) / 1e9, 3)
+        roof["note"] = ("MSM is integer-ALU-bound (254-bit Montgomery madds), not HBM-bound: see DESIGN.md.  avg_launch_ms is "
+                        "the HIP-event duration inside the timed region, where this kernel shares the GPU with the other "
+                        "MSM lanes and in-flight proofs")
         extra["msm_window_bits"] = c
         extra["msm_tables"] = W
 

@@ -218,7 +218,8 @@ int32_t g16_verify(g16_ctx* ctx, const g16_vkey* key, const g16_proof* proofs, c
 int32_t g16_pairing(g16_ctx* ctx, const void* g1_points, const void* g2_points, size_t n, void* out_gt);
 
 /* ---- profiling ---------------------------------------------------------------------------------- */
-/* when enabled, every kernel launch is bracketed by HIP events on the context's stream */
+/* on = 1: every kernel launch is bracketed by HIP events on the stream it is launched on; on = 2: only the
+ * bucket-accumulation kernels (cheap enough to leave on inside a timed region); on = 0: off */
 int32_t g16_profile_enable(g16_ctx* ctx, int32_t on);
 int32_t g16_profile_reset(g16_ctx* ctx);
 /* writes a JSON object {"kernel": {"calls": k, "total_ms": t}, ...} into buf (NUL-terminated) */

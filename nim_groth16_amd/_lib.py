@@ -265,8 +265,9 @@ class Context:
                                           n, out))
         return out.raw[:GT_BYTES * n]
 
-    def profile(self, on: bool):
-        self._check(self._lib.g16_profile_enable(self._h, 1 if on else 0))
+    def profile(self, on):
+        """False/0: off; True/1: HIP events around every kernel; 2: around the bucket-accumulation kernels only"""
+        self._check(self._lib.g16_profile_enable(self._h, int(on)))
 
     def profile_reset(self):
         self._check(self._lib.g16_profile_reset(self._h))

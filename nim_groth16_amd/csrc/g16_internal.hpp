@@ -65,6 +65,7 @@ struct g16_ctx {
   uint32_t coset_log2n[2] = {0xffffffffu, 0xffffffffu};
   // profiling
   bool profiling = false;
+  bool prof_accum_only = false;   // g16_profile_enable(ctx, 2): only the bucket-accumulation kernels
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> free_events;
 };
@@ -99,7 +100,8 @@ struct ProfScope {
   ProfEntry e;
   hipStream_t st;
   ProfScope(g16_ctx* c, const char* name, hipStream_t stream = nullptr)
-      : ctx(c), on(c->profiling), st(stream ? stream : c->stream) {
+      : ctx(c), on(c->profiling && (!c->prof_accum_only || strncmp(name, "msm_accum", 9) == 0)),
+        st(stream ? stream : c->stream) {
     if (!on) return;
     e.name = name;
     auto get = [&](hipEvent_t& ev) {

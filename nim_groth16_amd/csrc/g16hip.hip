@@ -114,6 +114,7 @@ extern "C" int32_t g16_ctx_synchronize(g16_ctx* ctx) {
 extern "C" int32_t g16_profile_enable(g16_ctx* ctx, int32_t on) {
   if (!ctx) return G16_EINVAL;
   ctx->profiling = on != 0;
+  ctx->prof_accum_only = on == 2;
   return G16_OK;
 }
 extern "C" int32_t g16_profile_reset(g16_ctx* ctx) {
