@@ -113,6 +113,43 @@ struct Ec29<G1> {
     acc.y = F::dot2(nR, d, yn, ppp);
     acc.x = x3;
   }
+  // the exceptional cases of a general addition: through the 8x32 formulas
+  static FF_HD_COLD Acc add_exceptional(Acc a, Acc b) {
+    g1_acc sa = to_std(a);
+    G1::add(sa, to_std(b));
+    return acc_from_std(sa);
+  }
+  // acc += q, both XYZZ (add-2008-s): 10 mul + 2 sqr + one 2-term dot; mirrored by g1_add in tools/ff29_model.py
+  static FF_HD void add(Acc& acc, const Acc& q) {
+    if (is_inf(q)) return;
+    if (is_inf(acc)) {
+      acc = q;
+      return;
+    }
+    fe29 u1 = F::mul(acc.x, q.zz);
+    fe29 u2 = F::mul(q.x, acc.zz);
+    fe29 s1 = F::mul(acc.y, q.zzz);
+    fe29 s2 = F::mul(q.y, acc.zzz);
+    fe29 nP = F::norm(F::subk<4, 1>(u2, u1));
+    fe29 nR = F::norm(F::subk<4, 1>(s2, s1));
+    if (F::maybe_zero(nP)) {
+      if (F::is_zero_exact<4>(nP)) {
+        acc = add_exceptional(acc, q);
+        return;
+      }
+    }
+    fe29 pp = F::sqr(nP);
+    fe29 ppp = F::mul(nP, pp);
+    fe29 qq = F::mul(u1, pp);
+    acc.zz = F::mul(F::mul(acc.zz, q.zz), pp);
+    acc.zzz = F::mul(F::mul(acc.zzz, q.zzz), ppp);
+    fe29 r2 = F::sqr(nR);
+    fe29 x3 = F::norm(F::subk2<8, 3>(r2, ppp, qq));
+    fe29 d = F::subk<16, 1>(qq, x3);
+    fe29 s1n = F::negk<4, 1>(s1);
+    acc.y = F::dot2(nR, d, s1n, ppp);
+    acc.x = x3;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -215,6 +252,46 @@ struct Ec29<G2> {
     fe29 ny1 = F::norm(F::negk<4, 1>(acc.y.c1));
     f2e29 y3{F::dot4(nR.c0, d.c0, nr1, d.c1, ny0, ppp.c0, acc.y.c1, ppp.c1),
              F::dot4(nR.c0, d.c1, nR.c1, d.c0, ny0, ppp.c1, ny1, ppp.c0)};
+    acc.x = x3;
+    acc.y = y3;
+  }
+  static FF_HD_COLD Acc add_exceptional(Acc a, Acc b) {
+    g2_acc sa = to_std(a);
+    G2::add(sa, to_std(b));
+    return acc_from_std(sa);
+  }
+  // acc += q, both XYZZ; mirrored by g2_add in tools/ff29_model.py
+  static FF_HD void add(Acc& acc, const Acc& q) {
+    if (is_inf(q)) return;
+    if (is_inf(acc)) {
+      acc = q;
+      return;
+    }
+    f2e29 u1 = f2mul<16>(acc.x, q.zz);
+    f2e29 u2 = f2mul<16>(q.x, acc.zz);
+    f2e29 s1 = f2mul<4>(acc.y, q.zzz);
+    f2e29 s2 = f2mul<4>(q.y, acc.zzz);
+    f2e29 nP{F::norm(F::subk<4, 1>(u2.c0, u1.c0)), F::norm(F::subk<4, 1>(u2.c1, u1.c1))};
+    f2e29 nR{F::norm(F::subk<4, 1>(s2.c0, s1.c0)), F::norm(F::subk<4, 1>(s2.c1, s1.c1))};
+    if (F::maybe_zero(nP.c0) && F::maybe_zero(nP.c1)) {
+      if (F::is_zero_exact<4>(nP.c0) && F::is_zero_exact<4>(nP.c1)) {
+        acc = add_exceptional(acc, q);
+        return;
+      }
+    }
+    f2e29 pp = f2sqr<8>(nP);
+    f2e29 ppp = f2mul<8>(nP, pp);
+    f2e29 qq = f2mul<4>(u1, pp);
+    acc.zz = f2mul<4>(f2mul<4>(acc.zz, q.zz), pp);
+    acc.zzz = f2mul<4>(f2mul<4>(acc.zzz, q.zzz), ppp);
+    f2e29 r2 = f2sqr<8>(nR);
+    f2e29 x3{F::norm(F::subk2<8, 3>(r2.c0, ppp.c0, qq.c0)), F::norm(F::subk2<8, 3>(r2.c1, ppp.c1, qq.c1))};
+    f2e29 d{F::norm(F::subk<16, 1>(qq.c0, x3.c0)), F::norm(F::subk<16, 1>(qq.c1, x3.c1))};
+    fe29 nr1 = F::norm(F::negk<8, 1>(nR.c1));
+    fe29 ns0 = F::norm(F::negk<4, 1>(s1.c0));
+    fe29 ns1 = F::norm(F::negk<4, 1>(s1.c1));
+    f2e29 y3{F::dot4(nR.c0, d.c0, nr1, d.c1, ns0, ppp.c0, s1.c1, ppp.c1),
+             F::dot4(nR.c0, d.c1, nR.c1, d.c0, ns0, ppp.c1, ns1, ppp.c0)};
     acc.x = x3;
     acc.y = y3;
   }

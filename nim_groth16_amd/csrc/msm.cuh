@@ -435,7 +435,7 @@ template <class C>
 __global__ void __launch_bounds__(MSM_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : G16_G2_WAVES)
 msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __restrict__ entries,
           const uint32_t* __restrict__ offset, const uint2* __restrict__ xseg, const uint32_t* __restrict__ info,
-          const uint32_t* __restrict__ perm, MsmParams P, typename C::Acc* __restrict__ partial) {
+          const uint32_t* __restrict__ perm, MsmParams P, typename Ec29<C>::Acc* __restrict__ partial) {
   using E = Ec29<C>;
   // task order = dispatch order: the extra segments of split buckets (the longest tasks, L entries each)
   // first, then the buckets by descending size, so that no long task is left for the tail of the launch
@@ -461,7 +461,7 @@ msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __re
     const uint32_t e = entries[j];   // point index (table-major) | sign in bit 31
     E::madd(acc, points + (e & 0x7fffffffu), e >> 31);
   }
-  partial[slot] = E::to_std(acc);
+  partial[slot] = acc;   // stays in the reduced-radix form: msm_heavy / msm_reduce1 consume it as is
 }
 
 // affine points in the reference layout (64 / 128 B, Montgomery R = 2^256) -> reduced-radix table entries
@@ -491,27 +491,32 @@ __device__ __forceinline__ typename C::Acc block_sum(typename C::Acc v, typename
   return r;
 }
 
-constexpr int HEAVY_BLOCK = 256;
+// the bucket partials between msm_accum and msm_reduce1 are reduced-radix XYZZ (Ec29<C>::Acc: 144 B G1, 288 B G2);
+// HEAVY_BLOCK threads x one partial each must fit the LDS budget of a workgroup
 template <class C>
-__global__ void __launch_bounds__(HEAVY_BLOCK) msm_heavy(const uint32_t* __restrict__ heavy,
+constexpr int heavy_block() { return sizeof(typename C::Aff) == 64 ? 256 : 128; }
+template <class C>
+__global__ void __launch_bounds__(heavy_block<C>()) msm_heavy(const uint32_t* __restrict__ heavy,
                                                          const uint32_t* __restrict__ info,
                                                          const uint32_t* __restrict__ offset,
                                                          const uint32_t* __restrict__ xoff, MsmParams P,
-                                                         typename C::Acc* __restrict__ partial) {
+                                                         typename Ec29<C>::Acc* __restrict__ partial) {
+  using E = Ec29<C>;
+  constexpr int HEAVY_BLOCK = heavy_block<C>();
   extern __shared__ __align__(16) unsigned char smem[];
-  typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
+  typename E::Acc* sh = reinterpret_cast<typename E::Acc*>(smem);
   const uint32_t nheavy = info[2];
   for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
     uint32_t b = heavy[h];
     uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
     if (e < HEAVY_MIN) continue;   // left to msm_heavy_small (uniform per workgroup: no barrier is skipped unevenly)
-    typename C::Acc acc = C::acc_inf();
+    typename E::Acc acc = E::acc_inf();
     // segment 0 lives at partial[b]; segments 1..e at partial[nbuckets + x0 + s - 1]
     for (uint32_t s = threadIdx.x; s <= e; s += HEAVY_BLOCK) {
       uint32_t idx = s == 0 ? b : P.nbuckets + x0 + s - 1;
-      C::add(acc, partial[idx]);
+      E::add(acc, partial[idx]);
     }
-    typename C::Acc r = block_sum<C, HEAVY_BLOCK>(acc, sh);
+    typename E::Acc r = block_sum<E, HEAVY_BLOCK>(acc, sh);
     if (threadIdx.x == 0) partial[b] = r;
   }
 }
@@ -522,14 +527,15 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_heavy_small(const uint32_t* __r
                                                              const uint32_t* __restrict__ info,
                                                              const uint32_t* __restrict__ offset,
                                                              const uint32_t* __restrict__ xoff, MsmParams P,
-                                                             typename C::Acc* __restrict__ partial) {
+                                                             typename Ec29<C>::Acc* __restrict__ partial) {
+  using E = Ec29<C>;
   const uint32_t nheavy = info[2];
   for (uint32_t h = blockIdx.x * MSM_BLOCK + threadIdx.x; h < nheavy; h += gridDim.x * MSM_BLOCK) {
     const uint32_t b = heavy[h];
     const uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
     if (e >= HEAVY_MIN) continue;
-    typename C::Acc acc = partial[b];
-    for (uint32_t k = 0; k < e; ++k) C::add(acc, partial[P.nbuckets + x0 + k]);
+    typename E::Acc acc = partial[b];
+    for (uint32_t k = 0; k < e; ++k) E::add(acc, partial[P.nbuckets + x0 + k]);
     partial[b] = acc;
   }
 }
@@ -538,21 +544,22 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_heavy_small(const uint32_t* __r
 // stage 1: thread per chunk of RC consecutive buckets: R_j = sum B_k, A_j = sum (k - j*RC) B_k
 constexpr int RED_CHUNK = 16;
 template <class C>
-__global__ void __launch_bounds__(MSM_BLOCK) msm_reduce1(const typename C::Acc* __restrict__ partial,
+__global__ void __launch_bounds__(MSM_BLOCK) msm_reduce1(const typename Ec29<C>::Acc* __restrict__ partial,
                                                          const uint32_t* __restrict__ offset, uint32_t nbuckets,
                                                          typename C::Acc* __restrict__ chunkR,
                                                          typename C::Acc* __restrict__ chunkA) {
+  using E = Ec29<C>;   // running sums in the reduced-radix field; the chunk sums leave in the standard layout
   uint32_t j = blockIdx.x * MSM_BLOCK + threadIdx.x;
   uint32_t b0 = j * RED_CHUNK;
   if (b0 >= nbuckets) return;
-  typename C::Acc run = C::acc_inf(), acc = C::acc_inf();
+  typename E::Acc run = E::acc_inf(), acc = E::acc_inf();
   for (int k = RED_CHUNK - 1; k >= 0; --k) {
     uint32_t b = b0 + k;
-    if (b < nbuckets && offset[b + 1] != offset[b]) C::add(run, partial[b]);
-    C::add(acc, run);
+    if (b < nbuckets && offset[b + 1] != offset[b]) E::add(run, partial[b]);
+    E::add(acc, run);
   }
-  chunkR[j] = run;
-  chunkA[j] = acc;
+  chunkR[j] = E::to_std(run);
+  chunkA[j] = E::to_std(acc);
 }
 // stage 2: one workgroup per reduction set (a window, or a slice of the merged bucket set) over its M chunks
 // (chunk m holds buckets m*RC+1 .. (m+1)*RC of the set):

@@ -14,7 +14,8 @@ int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, ui
 static int32_t msm_reduce(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc, const g16_ctx::MsmSort& S, int group,
                           const void* d_points, void* d_out_aff, void* d_out_acc) {
   const MsmParams& P = S.P;
-  const size_t asz = group == 1 ? 128 : 256;
+  const size_t asz = group == 1 ? 128 : 256;    // standard XYZZ (chunk sums and later)
+  const size_t psz29 = group == 1 ? 144 : 288;  // reduced-radix XYZZ (bucket partials: accumulate -> heavy -> reduce1)
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t r = o;
@@ -22,7 +23,7 @@ static int32_t msm_reduce(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc, const
     return r;
   };
   const size_t nchunks = P.nbuckets / RED_CHUNK;
-  const size_t o_partial = take(((size_t)P.nbuckets + P.max_extra) * asz), o_chunkR = take(nchunks * asz),
+  const size_t o_partial = take(((size_t)P.nbuckets + P.max_extra) * psz29), o_chunkR = take(nchunks * asz),
                o_chunkA = take(nchunks * asz), o_wsum = take((size_t)(2 * 64 + 2) * asz);
   int32_t rc = ensure(ctx, acc, o);
   if (rc) return rc;

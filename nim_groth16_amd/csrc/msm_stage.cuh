@@ -14,7 +14,7 @@ static int32_t stage_accum(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort&
   const uint32_t ntask = P.nbuckets + P.max_extra;
   KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + MSM_BLOCK - 1) / MSM_BLOCK,
              MSM_BLOCK, 0, (const typename Ec29<C>::Tab*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
-             (typename C::Acc*)partial);
+             (typename Ec29<C>::Acc*)partial);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
@@ -23,9 +23,9 @@ template <class C>
 static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, void* partial_) {
   const MsmParams& P = S.P;
   const bool g2 = sizeof(typename C::Aff) == 128;
-  auto* partial = (typename C::Acc*)partial_;
-  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, HEAVY_BLOCK,
-             HEAVY_BLOCK * sizeof(typename C::Acc), S.heavy, S.info, S.offset, S.xoff, P, partial);
+  auto* partial = (typename Ec29<C>::Acc*)partial_;
+  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, heavy_block<C>(),
+             heavy_block<C>() * sizeof(typename Ec29<C>::Acc), S.heavy, S.info, S.offset, S.xoff, P, partial);
   KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy_small<C>, 256, MSM_BLOCK, 0, S.heavy, S.info,
              S.offset, S.xoff, P, partial);
   HIPCHK(ctx, hipGetLastError());
@@ -39,7 +39,7 @@ static int32_t stage_reduce1(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSor
   const bool g2 = sizeof(typename C::Aff) == 128;
   const size_t nchunks = P.nbuckets / RED_CHUNK;
   KLAUNCH_ON(ctx, st, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>,
-             (uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, (const typename C::Acc*)partial, S.offset,
+             (uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, (const typename Ec29<C>::Acc*)partial, S.offset,
              P.nbuckets, (typename C::Acc*)chunkR, (typename C::Acc*)chunkA);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;

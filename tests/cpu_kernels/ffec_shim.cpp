@@ -3,6 +3,7 @@
 #include "../../nim_groth16_amd/csrc/ec29.cuh"
 #include "../../nim_groth16_amd/csrc/pairing.cuh"
 #include <cstring>
+#include <vector>
 using namespace g16;
 
 template <class T> static T ld(const void* p) { T t; std::memcpy(&t, p, sizeof(T)); return t; }
@@ -21,6 +22,32 @@ static void sum29(int op, const void* pts, int n, void* out) {
     E::madd(acc, &t, op == 1 ? 1u : 0u);
   }
   st(out, C::to_affine(E::to_std(acc)));
+}
+
+// op 2: general XYZZ += XYZZ additions in the reduced-radix field: ((q0 + q1) + (q2 + q3)) + ... pairwise tree, so that
+// both operands are genuine accumulators
+template <class C>
+static void tree29(const void* pts, int n, void* out) {
+  using E = Ec29<C>;
+  std::vector<typename E::Acc> v;
+  const char* p = (const char*)pts;
+  for (int i = 0; i < n; ++i) {
+    typename E::Acc a = E::acc_inf();
+    const typename E::Tab t = E::tab_from_std(ld<typename C::Aff>(p + sizeof(typename C::Aff) * i));
+    E::madd(a, &t, 0u);
+    v.push_back(a);
+  }
+  while (v.size() > 1) {
+    std::vector<typename E::Acc> w;
+    for (size_t i = 0; i + 1 < v.size(); i += 2) {
+      typename E::Acc a = v[i];
+      E::add(a, v[i + 1]);
+      w.push_back(a);
+    }
+    if (v.size() & 1) w.push_back(v.back());
+    v.swap(w);
+  }
+  st(out, C::to_affine(v.empty() ? C::acc_inf() : E::to_std(v[0])));
 }
 
 extern "C" {
@@ -73,8 +100,8 @@ void shim_g1_sum(int op, const void* pts, int n, void* out) {
   }
   st(out, G1::to_affine(acc));
 }
-void shim_g1_sum29(int op, const void* pts, int n, void* out) { sum29<G1>(op, pts, n, out); }
-void shim_g2_sum29(int op, const void* pts, int n, void* out) { sum29<G2>(op, pts, n, out); }
+void shim_g1_sum29(int op, const void* pts, int n, void* out) { if (op == 2) tree29<G1>(pts, n, out); else sum29<G1>(op, pts, n, out); }
+void shim_g2_sum29(int op, const void* pts, int n, void* out) { if (op == 2) tree29<G2>(pts, n, out); else sum29<G2>(op, pts, n, out); }
 // op 0: to_std(mul(from_std a, from_std b))  1: to_std(sqr(from_std a))  2: to_std(from_std a)
 // 3: to_std(dot2(a,b,a,b)) = 2ab
 void shim_f29_op(int op, const void* a, const void* b, void* r) {

@@ -127,6 +127,7 @@ def test_reduced_radix_accumulate(shim, group):
             exp = C.add(exp, q)
         assert gsum(0, pts) == exp
         assert gsum(1, pts) == exp
+        assert gsum(2, pts) == exp      # pairwise tree of general XYZZ + XYZZ additions (bucket reduction)
 
 
 def test_reduced_radix_interval_model():

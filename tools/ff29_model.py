@@ -333,6 +333,112 @@ def check_g2(rnd):
     return log
 
 
+# ---------------------------------------------------------------------------------------------------------
+# general additions XYZZ += XYZZ (add-2008-s) used by the bucket-reduction kernels; both operands satisfy the
+# same invariants as above and so does the result
+# ---------------------------------------------------------------------------------------------------------
+def g1_add(A, Bq, log=None):
+    X1, Y1, ZZ1, ZZZ1 = A
+    X2, Y2, ZZ2, ZZZ2 = Bq
+    u1 = mont((X1, ZZ2))
+    u2 = mont((X2, ZZ1))
+    s1 = mont((Y1, ZZZ2))
+    s2 = mont((Y2, ZZZ1))
+    nP = norm(subk(u2, u1, (4, 1)))
+    nR = norm(subk(s2, s1, (4, 1)))
+    PP = sqr(nP)
+    PPP = mont((nP, PP))
+    Q = mont((u1, PP))
+    R2 = sqr(nR)
+    X3 = norm(subk(R2, PPP, (8, 3), twice=Q))
+    D = subk(Q, X3, (16, 1))
+    s1n = negk(s1, (4, 1))
+    Y3 = mont((nR, D), (s1n, PPP))
+    ZZ3 = mont((mont((ZZ1, ZZ2)), PP))
+    ZZZ3 = mont((mont((ZZZ1, ZZZ2)), PPP))
+    if log is not None:
+        log.update(u1=u1, nP=nP, nR=nR, PP=PP, PPP=PPP, Q=Q, X3=X3, Y3=Y3, ZZ3=ZZ3, ZZZ3=ZZZ3)
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def g2_add(A, Bq, log=None):
+    X1, Y1, ZZ1, ZZZ1 = A
+    X2, Y2, ZZ2, ZZZ2 = Bq
+    u1 = f2mul(X1, ZZ2, (16, 1))
+    u2 = f2mul(X2, ZZ1, (16, 1))
+    s1 = f2mul(Y1, ZZZ2, (4, 1))
+    s2 = f2mul(Y2, ZZZ1, (4, 1))
+    nP = tuple(norm(subk(u2[i], u1[i], (4, 1))) for i in range(2))
+    nR = tuple(norm(subk(s2[i], s1[i], (4, 1))) for i in range(2))
+    PP = f2sqr(nP, (8, 1))
+    PPP = f2mul(nP, PP, (8, 1))
+    Q = f2mul(u1, PP, (4, 1))
+    R2 = f2sqr(nR, (8, 1))
+    X3 = tuple(norm(subk(R2[i], PPP[i], (8, 3), twice=Q[i])) for i in range(2))
+    D = tuple(norm(subk(Q[i], X3[i], (16, 1))) for i in range(2))
+    nr1 = norm(negk(nR[1], (8, 1)))
+    ns0 = norm(negk(s1[0], (4, 1)))
+    ns1 = norm(negk(s1[1], (4, 1)))
+    Y3 = (mont((nR[0], D[0]), (nr1, D[1]), (ns0, PPP[0]), (s1[1], PPP[1])),
+          mont((nR[0], D[1]), (nR[1], D[0]), (ns0, PPP[1]), (ns1, PPP[0])))
+    ZZ3 = f2mul(f2mul(ZZ1, ZZ2, (4, 1)), PP, (4, 1))
+    ZZZ3 = f2mul(f2mul(ZZZ1, ZZZ2, (4, 1)), PPP, (4, 1))
+    if log is not None:
+        log.update(u1=u1, nP=nP, nR=nR, PP=PP, PPP=PPP, Q=Q, X3=X3, Y3=Y3, ZZ3=ZZ3, ZZZ3=ZZZ3)
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def check_adds(rnd):
+    def pick(k):
+        return E.normalized(rnd.choice([0, k * p, rnd.randrange(k * p + 1)]), k * p)
+
+    def m2(a, b):
+        return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+    def s2_(a, b):
+        return ((a[0] - b[0]) % p, (a[1] - b[1]) % p)
+
+    logs = []
+    for group, inv, fn in ((1, G1_INV, g1_add), (2, G2_INV, g2_add)):
+        for trial in range(100):
+            if group == 1:
+                A = tuple(pick(inv[n]) for n in ("X", "Y", "ZZ", "ZZZ"))
+                Bq = tuple(pick(inv[n]) for n in ("X", "Y", "ZZ", "ZZZ"))
+            else:
+                A = tuple((pick(inv[n]), pick(inv[n])) for n in ("X", "Y", "ZZ", "ZZZ"))
+                Bq = tuple((pick(inv[n]), pick(inv[n])) for n in ("X", "Y", "ZZ", "ZZZ"))
+            log = {}
+            out = fn(A, Bq, log)
+            for nm, o in zip(("X", "Y", "ZZ", "ZZZ"), out):
+                for c in (o if group == 2 else (o,)):
+                    assert c.vb <= inv[nm] * p, (group, nm, c.vb / p)
+                    assert all(m <= MASK for m in c.lb[:L - 1])
+            if group == 1:
+                x1, y1, z1, t1 = map(fval, A)
+                x2, y2, z2, t2 = map(fval, Bq)
+                U1, U2, S1, S2 = x1 * z2 % p, x2 * z1 % p, y1 * t2 % p, y2 * t1 % p
+                P_, R_ = (U2 - U1) % p, (S2 - S1) % p
+                pp, ppp = P_ * P_ % p, P_ ** 3 % p
+                q = U1 * pp % p
+                x3 = (R_ * R_ - ppp - 2 * q) % p
+                exp = (x3, (R_ * (q - x3) - S1 * ppp) % p, z1 * z2 * pp % p, t1 * t2 * ppp % p)
+                assert tuple(map(fval, out)) == exp
+            else:
+                x1, y1, z1, t1 = map(f2val, A)
+                x2, y2, z2, t2 = map(f2val, Bq)
+                U1, U2, S1, S2 = m2(x1, z2), m2(x2, z1), m2(y1, t2), m2(y2, t1)
+                P_, R_ = s2_(U2, U1), s2_(S2, S1)
+                pp = m2(P_, P_)
+                ppp = m2(P_, pp)
+                q = m2(U1, pp)
+                rr = m2(R_, R_)
+                x3 = ((rr[0] - ppp[0] - 2 * q[0]) % p, (rr[1] - ppp[1] - 2 * q[1]) % p)
+                exp = (x3, s2_(m2(R_, s2_(q, x3)), m2(S1, ppp)), m2(m2(z1, z2), pp), m2(m2(t1, t2), ppp))
+                assert tuple(map(f2val, out)) == exp
+        logs.append(log)
+    return logs
+
+
 def main():
     rnd = random.Random(7)
     # plain products and squares at the documented input bound (13p x 13p)
@@ -345,6 +451,9 @@ def main():
     print("G1 madd: invariant", G1_INV, "holds;", {k: f"{v.vb / p:.2f}p" for k, v in lg.items()})
     lg = check_g2(rnd)
     print("G2 madd: invariant", G2_INV, "holds;", {k: f"{max(c.vb for c in v) / p:.2f}p" for k, v in lg.items()})
+    for nm, lg in zip(("G1 add", "G2 add"), check_adds(rnd)):
+        print(nm + ": invariant holds;", {k: f"{max(c.vb for c in (v if isinstance(v, tuple) else (v,))) / p:.2f}p"
+                                          for k, v in lg.items()})
     print("largest column bound: 2^%.3f" % (maxcol.bit_length() - 1 + (maxcol / (1 << (maxcol.bit_length() - 1)) - 1)))
     print("K forms used (mult, lift):", sorted(USED_K))
 
