@@ -62,9 +62,22 @@ struct Pairing {
 #pragma unroll 1
     for (int k = 0; k < 6; ++k) r.g[k] = Fp2::add(lo[k], mul_xi(hi[k]));
   }
-  static FF_HD void sqr(fp12_t& r, const fp12_t& a) {
-    fp12_t t = a;
-    mul(r, t, t);
+  // square: 15 doubled cross products + 6 squares instead of 36 products
+  static FF_HD_COLD void sqr(fp12_t& r, const fp12_t& a) {
+    fp2_t lo[6], hi[6];
+    for (int k = 0; k < 6; ++k) lo[k] = hi[k] = Fp2::zero();
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll 1
+      for (int j = i; j < 6; ++j) {
+        fp2_t t = i == j ? f2sqr(a.g[i]) : Fp2::dbl(f2mul(a.g[i], a.g[j]));
+        int k = i + j;
+        if (k < 6) lo[k] = Fp2::add(lo[k], t);
+        else hi[k - 6] = Fp2::add(hi[k - 6], t);
+      }
+    }
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) r.g[k] = Fp2::add(lo[k], mul_xi(hi[k]));
   }
   // r = f * (l0 + l1 w + l3 w^3), l0 in Fp
   static FF_HD_COLD void mul_line(fp12_t& f, const u256& l0, const fp2_t& l1, const fp2_t& l3) {
