@@ -18,6 +18,24 @@
 #pragma once
 #include "ff.cuh"
 
+// Every multiply-add of a column is pinned behind the previous one by an empty (non-volatile) asm, so that the
+// column sum is ONE serial v_mad_u64_u32 chain starting from the carry of the previous column.  Left alone, the
+// compiler starts each column from zero (shorter critical path, which 4 waves/SIMD do not need) and joins it with
+// the carry through an extra 64-bit add per column (144 v_lshl_add_u64 per mixed addition).  The asm costs an
+// s_nop each (hazard padding), still a net win where occupancy hides the longer chain: msm_accum_g1 (4 waves/SIMD)
+// 1.007 -> 0.956 ms; the G2 accumulate (2 waves/SIMD) and the reduce kernels (1 wave/SIMD) get slower, so only
+// msm_g1_accum.hip is built with -DG16_F29_SERIAL (Makefile).  (A *volatile* asm orders all field operations
+// against each other and made the kernel 3x slower.)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_F29_SERIAL)
+#define F29_MAC(acc, a, b)              \
+  do {                                  \
+    acc += (uint64_t)(a) * (b);         \
+    asm("" : "+v"(acc));                \
+  } while (0)
+#else
+#define F29_MAC(acc, a, b) acc += (uint64_t)(a) * (b)
+#endif
+
 namespace g16 {
 
 struct fe29 {
@@ -97,17 +115,17 @@ struct Fp29 {
       const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
 #pragma unroll
       for (int i = lo; i <= hi; ++i) {
-        acc += (uint64_t)a0.v[i] * b0.v[k - i];
-        if constexpr (NP > 1) acc += (uint64_t)a1.v[i] * b1.v[k - i];
-        if constexpr (NP > 2) acc += (uint64_t)a2.v[i] * b2.v[k - i];
-        if constexpr (NP > 3) acc += (uint64_t)a3.v[i] * b3.v[k - i];
+        F29_MAC(acc, a0.v[i], b0.v[k - i]);
+        if constexpr (NP > 1) F29_MAC(acc, a1.v[i], b1.v[k - i]);
+        if constexpr (NP > 2) F29_MAC(acc, a2.v[i], b2.v[k - i]);
+        if constexpr (NP > 3) F29_MAC(acc, a3.v[i], b3.v[k - i]);
       }
 #pragma unroll
       for (int i = lo; i <= hi; ++i)
-        if (!(k < L && i == k)) acc += (uint64_t)m[i] * PL.v[k - i];
+        if (!(k < L && i == k)) F29_MAC(acc, m[i], PL.v[k - i]);
       if (k < L) {
         m[k] = ((uint32_t)acc * N0) & MASK;
-        acc += (uint64_t)m[k] * PL.v[0];
+        F29_MAC(acc, m[k], PL.v[0]);
       } else {
         r.v[k - L] = (uint32_t)acc & MASK;
       }
@@ -136,15 +154,15 @@ struct Fp29 {
       const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
 #pragma unroll
       for (int i = lo; i <= hi; ++i) {
-        if (i < k - i) acc += (uint64_t)a.v[i] * a2[k - i];
-        if (i == k - i) acc += (uint64_t)a.v[i] * a.v[i];
+        if (i < k - i) F29_MAC(acc, a.v[i], a2[k - i]);
+        if (i == k - i) F29_MAC(acc, a.v[i], a.v[i]);
       }
 #pragma unroll
       for (int i = lo; i <= hi; ++i)
-        if (!(k < L && i == k)) acc += (uint64_t)m[i] * PL.v[k - i];
+        if (!(k < L && i == k)) F29_MAC(acc, m[i], PL.v[k - i]);
       if (k < L) {
         m[k] = ((uint32_t)acc * N0) & MASK;
-        acc += (uint64_t)m[k] * PL.v[0];
+        F29_MAC(acc, m[k], PL.v[0]);
       } else {
         r.v[k - L] = (uint32_t)acc & MASK;
       }
