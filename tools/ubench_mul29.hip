@@ -27,8 +27,8 @@ template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k29d(fe29* io, int iters) {   // dot product (ab+cd)/R
   fe29 x = io[threadIdx.x & 63], y = io[64 + (threadIdx.x & 63)], z = io[(threadIdx.x + 7) & 63], w = io[(threadIdx.x + 9) & 63];
   x.v[0] ^= blockIdx.x & 0xff;
-  for (int i = 0; i < iters; ++i) { x = Fp29::dot2(x, y, z, w); y = Fp29::dot2(y, x, w, z); }
-  if (x.v[0] == 0x12345u) io[0] = y;
+  for (int i = 0; i < iters; ++i) { x = Fp29::dot2(x, y, z, w); z = Fp29::dot2(z, w, x, y); }   // all operands loop-variant
+  if (x.v[0] == 0x12345u) io[0] = z;
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k29s(fe29* io, int iters) {   // squaring
@@ -41,7 +41,7 @@ template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k32d(u256* io, int iters) {
   u256 x = io[threadIdx.x & 63], y = io[64 + (threadIdx.x & 63)], z = io[(threadIdx.x + 7) & 63], w = io[(threadIdx.x + 9) & 63];
   x.v[0] ^= blockIdx.x;
-  for (int i = 0; i < iters; ++i) { x = Fp::mul2(x, y, z, w); y = Fp::mul2(y, x, w, z); }
+  for (int i = 0; i < iters; ++i) { x = Fp::mul2(x, y, z, w); z = Fp::mul2(z, w, x, y); }
   if (x.v[0] == 0x12345u) io[0] = y;
 }
 
