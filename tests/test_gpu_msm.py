@@ -145,6 +145,30 @@ def test_msm_registered_repeated_and_opposite_points(ctx, orc, group):
             h.release()
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_equal_and_opposite_bucket_sums(ctx, orc, group):
+    """the SAME point alone in neighbouring buckets (small distinct scalars): the running sums of msm_reduce1 then add
+    equal / opposite bucket sums -- the exact P+P and P-P paths of the general reduced-radix addition (Ec29::add)"""
+    psz = PSZ[group]
+    _, pts = I.points_with_logs(orc, group, 2, seed=91)
+    P0, P1 = pts[:psz], pts[psz:]
+    C = o.G1 if group == 1 else o.G2
+    dec, enc = (o.g1_from_bytes, o.g1_to_bytes) if group == 1 else (o.g2_from_bytes, o.g2_to_bytes)
+    neg0 = enc(C.neg(dec(P0)))
+    cases = [([5, 6], [P0, P0]), ([6, 5], [P0, neg0]), (list(range(1, 17)), [P0] * 16),
+             (list(range(1, 33)), [P0, neg0] * 16), ([3, 3, 4, 4, 7], [P0, P1, P0, P1, neg0]),
+             ([1, 2, 4, 8, 16, 32], [P0] * 6)]
+    for sc, pl in cases:
+        sb, pb = I.fr_mont_bytes(sc), b"".join(pl)
+        exp = orc.msm_naive(group, sb, pb)
+        assert ctx.msm(group, sb, pb, len(sc)) == exp, sc
+        h = ctx.register_points(group, pb, len(pl))
+        try:
+            assert ctx.msm_points(h, sb) == exp, sc
+        finally:
+            h.release()
+
+
 def test_msm_registered_empty(ctx):
     h = ctx.register_points(1, b"", 0)
     assert ctx.msm_points(h, b"") == INF[1]
