@@ -72,12 +72,19 @@ def test_msm_mid_vs_oracle_pippenger(ctx, orc, group, n, dist):
     assert got == I.expected_from_logs(group, sc, ks)
 
 
-def test_msm_skewed_single_bucket(ctx, orc):
-    """every scalar equal: one bucket per window holds all N entries (heavy-bucket path)."""
-    n = 20000
-    ks, pts = I.points_with_logs(orc, 1, n, seed=51)
-    sc = [0x1234567] * n
-    assert ctx.msm(1, I.fr_mont_bytes(sc), pts, n) == I.expected_from_logs(1, sc, ks)
+@pytest.mark.parametrize("group,n", [(1, 20000), (2, 6000)])
+def test_msm_skewed_single_bucket(ctx, orc, group, n):
+    """every scalar equal: one bucket per window holds all N entries (heavy-bucket path: workgroup LDS tree of
+    reduced-radix partials), one-shot and registered; then a mix of a few heavy and many light buckets"""
+    ks, pts = I.points_with_logs(orc, group, n, seed=51)
+    for sc in ([0x1234567] * n, [(7, 1 << 40, 3)[i % 3] if i % 5 else I.uniform_scalars(1, i)[0] for i in range(n)]):
+        exp = I.expected_from_logs(group, sc, ks)
+        assert ctx.msm(group, I.fr_mont_bytes(sc), pts, n) == exp
+        h = ctx.register_points(group, pts, n)
+        try:
+            assert ctx.msm_points(h, I.fr_mont_bytes(sc)) == exp
+        finally:
+            h.release()
 
 
 def test_msm_partials_sum(ctx, orc):
