@@ -5,4 +5,4 @@ from .container import parseContainer, writeContainer  # noqa: F401
 from .zkey import parseZKey, writeZKey  # noqa: F401
 from .witness import parseWitness, writeWitness  # noqa: F401
 from .r1cs import parseR1CS, writeR1CS  # noqa: F401
-from .export_json import exportProof, exportPublicIO  # noqa: F401
+from .export_json import exportProof, exportPublicIO, exportVKey  # noqa: F401

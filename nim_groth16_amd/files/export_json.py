@@ -60,3 +60,25 @@ def exportProof(fpath: str, prf: Proof) -> None:
         f.write(', "pi_c":\n')
         _writeG1(f, prf.pi_c)
         f.write("}\n")
+
+
+def exportVKey(fpath: str, vkey) -> None:
+    """snarkjs `verification_key.json` for a VKey (verifier.py).  NOT in the reference (it only exports keys to Sage,
+    files/export_sage.nim:36-60; snarkjs users run `snarkjs zkey export verificationkey`): needed so that proofs of
+    fake-setup keys can be checked with `snarkjs groth16 verify vkey.json public.json proof.json`.  `vk_alphabeta_12`
+    is omitted: snarkjs recomputes the pairing from vk_alpha_1 / vk_beta_2 and does not read it when verifying."""
+    import json
+
+    def g1(p):
+        return [str(_fp(p[0:32])), str(_fp(p[32:64])), "1"]
+
+    def g2(p):
+        return [[str(_fp(p[0:32])), str(_fp(p[32:64]))], [str(_fp(p[64:96])), str(_fp(p[96:128]))], ["1", "0"]]
+    s = vkey.spec
+    ic = vkey.pointsIC
+    doc = {"protocol": "groth16", "curve": vkey.curve, "nPublic": vkey.npubs,
+           "vk_alpha_1": g1(s.alpha1), "vk_beta_2": g2(s.beta2), "vk_gamma_2": g2(s.gamma2), "vk_delta_2": g2(s.delta2),
+           "IC": [g1(ic[i:i + 64]) for i in range(0, len(ic), 64)]}
+    with open(fpath, "w") as f:
+        json.dump(doc, f, indent=1)
+        f.write("\n")

@@ -90,3 +90,18 @@ def test_export_json(tmp_path):
     assert [[int(x) for x in row] for row in d["pi_b"]] == [list(ref.pi_b[0]), list(ref.pi_b[1]), [1, 0]]
     assert [int(x) for x in d["pi_c"]] == [ref.pi_c[0], ref.pi_c[1], 1]
     assert [int(x) for x in json.load(open(ij))] == [2023, 1022]                            # constant 1 skipped
+
+
+def test_export_vkey_json(tmp_path):
+    """snarkjs verification_key.json shape (an addition: the reference has no JSON key export)"""
+    from nim_groth16_amd.files import exportVKey
+    from nim_groth16_amd.verifier import extractVKey
+    zk, oz = _toy_zkey()
+    path = str(tmp_path / "vkey.json")
+    exportVKey(path, extractVKey(zk))
+    d = json.load(open(path))
+    assert d["protocol"] == "groth16" and d["curve"] == "bn128" and d["nPublic"] == 2 and len(d["IC"]) == 3
+    assert [int(x) for x in d["vk_alpha_1"]] == [oz.alpha1[0], oz.alpha1[1], 1]
+    assert [[int(x) for x in row] for row in d["vk_delta_2"]] == [list(oz.delta2[0]), list(oz.delta2[1]), [1, 0]]
+    assert [[int(x) for x in row] for row in d["vk_gamma_2"]] == [list(oz.gamma2[0]), list(oz.gamma2[1]), [1, 0]]
+    assert [int(x) for x in d["IC"][2]] == [oz.pointsIC[2][0], oz.pointsIC[2][1], 1]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prove from circom/snarkjs artifacts on the GPU (the `-p` path of the reference CLI, cli/cli_main.nim:162-231):
-    python tools/prove_files.py --zkey circuit.zkey --wtns witness.wtns -o proof.json -i public.json
+    python tools/prove_files.py --zkey circuit.zkey --wtns witness.wtns -o proof.json -i public.json [-k vkey.json] [-y]
 The outputs are snarkjs-compatible (`snarkjs groth16 verify vkey.json public.json proof.json`)."""
 import argparse
 import os
@@ -23,6 +23,7 @@ def main():
     ap.add_argument("-i", "--io", default="public.json")
     ap.add_argument("-n", "--nomask", action="store_true", help="trivial mask r = s = 0 (cli_main.nim -n)")
     ap.add_argument("-t", "--time", action="store_true")
+    ap.add_argument("-k", "--vkey", default=None, help="also write the verification key as snarkjs verification_key.json")
     ap.add_argument("-y", "--verify", action="store_true",
                     help="also verify the proof against the zkey's verification key (cli_main.nim -y)")
     args = ap.parse_args()
@@ -38,6 +39,10 @@ def main():
     t3 = time.time()
     exportProof(args.output, proof)
     exportPublicIO(args.io, proof)
+    if args.vkey:
+        from nim_groth16_amd import extractVKey
+        from nim_groth16_amd.files import exportVKey
+        exportVKey(args.vkey, extractVKey(zkey))
     if args.verify:
         from nim_groth16_amd import extractVKey, verifyProof
         ok = verifyProof(extractVKey(zkey), proof, ctx)
