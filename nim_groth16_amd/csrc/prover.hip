@@ -285,11 +285,15 @@ extern "C" int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* k, const voi
     for (int i = 1; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, ctx->ev_b, 0));
     if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, ctx->sort[0], k->B2->d_tables, nullptr, slots + PART_B2)))
       return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[0].stream, L[0].acc, ctx->sort[0], k->A1->d_tables, nullptr, slots + PART_A)))
+    // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES = three digits from {0, 2, 3} (experiments)
+    int la = 0, lb = 2, lc = 3;
+    if (const char* e = getenv("G16_G1_LANES"))
+      if (strlen(e) == 3 && strspn(e, "023") == 3) la = e[0] - '0', lb = e[1] - '0', lc = e[2] - '0';
+    if ((rc = g16_msm_reduce_g1(ctx, L[la].stream, L[la].acc, ctx->sort[0], k->A1->d_tables, nullptr, slots + PART_A)))
       return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[2].stream, L[2].acc, ctx->sort[0], k->B1->d_tables, nullptr, slots + PART_B1)))
+    if ((rc = g16_msm_reduce_g1(ctx, L[lb].stream, L[lb].acc, ctx->sort[0], k->B1->d_tables, nullptr, slots + PART_B1)))
       return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[3].stream, L[3].acc, ctx->sort[0], k->C1->d_tables, nullptr, slots + PART_C)))
+    if ((rc = g16_msm_reduce_g1(ctx, L[lc].stream, L[lc].acc, ctx->sort[0], k->C1->d_tables, nullptr, slots + PART_C)))
       return rc;
     for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipEventRecord(L[i].done, L[i].stream));
   }
