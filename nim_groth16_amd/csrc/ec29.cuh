@@ -1,7 +1,9 @@
 // Bucket accumulation arithmetic on the reduced-radix field of ff29.cuh: XYZZ accumulator += affine table point
-// (madd-2008-s, 7M + 2S + one 2-term dot product in G1), for G1 (Fp) and G2 (Fp2 = Fp[u]/(u^2+1)).
+// (madd-2008-s: 6M + 2S + one 2-term dot product in G1) and XYZZ += XYZZ (add-2008-s, for the bucket partials of
+// msm_heavy / msm_reduce1), for G1 (Fp) and G2 (Fp2 = Fp[u]/(u^2+1)).
 //
-// The operation sequences below are mirrored line by line by g1_madd / g2_madd in tools/ff29_model.py, which
+// The operation sequences below are mirrored line by line by g1_madd / g2_madd / g1_add / g2_add in
+// tools/ff29_model.py, which
 // proves on worst-case bounds that no column or limb overflows and that the loop invariant
 //     G1: X < 10p, Y,ZZ,ZZZ <= 2p        G2 (per component): X < 12p, Y,ZZ,ZZZ <= 3p      (all normalized)
 // is preserved.  Table points are canonical (< p).  Exactly as in ec.cuh, P + P and P - P are detected and

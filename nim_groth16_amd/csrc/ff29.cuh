@@ -8,13 +8,13 @@
 // measured (tools/ubench_mul29.hip), and a dedicated squaring and multi-term dot products come for free.
 //
 // Values are lazily reduced: limbs may exceed 29 bits and values may exceed p, within bounds that are stated
-// at each function and PROVEN for the two mixed-addition sequences by the interval model tools/ff29_model.py
+// at each function and PROVEN for the mixed-addition and general-addition sequences by the interval model tools/ff29_model.py
 // (it executes the same operation sequence on worst-case bounds and checks every 64-bit column, every 32-bit
 // limb and the loop invariant).  "normalized" = limbs 0..7 < 2^29; the top limb carries whatever is left.
 //
-// The representation never leaves the accumulate kernel family: point tables are converted once at
-// registration (Ec29::from_std) and bucket sums are converted back to the 8x32 / R=2^256 layout of ff.cuh
-// (Ec29::to_std) before the reduction kernels see them.
+// The representation stays inside the accumulate -> heavy -> reduce1 kernels: point tables are converted once at
+// registration (Ec29::tab_from_std, packed 64/128-byte entries) and the 16-bucket chunk sums are converted back
+// to the 8x32 / R=2^256 layout of ff.cuh (Ec29::to_std) before the latency-bound tail (reduce2, fold) sees them.
 #pragma once
 #include "ff.cuh"
 
