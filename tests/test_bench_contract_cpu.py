@@ -1,0 +1,32 @@
+"""The committed bench line (profiles/) carries every field the driver's contract names, incl. the roofline and
+cpu_baseline objects -- a cheap guard against accidentally dropping one when bench.py is edited."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_step13_bench_2p20_final.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "proofs/s" and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong")
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"] * d["n_gpus"]) < 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
+
+
+def test_bench_source_emits_the_same_keys():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for k in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
+              '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"',
+              '"frac"', '"cores"', '"kind"', '"sample"'):
+        assert k in src, k
