@@ -7,8 +7,10 @@ fallback -- importing works anywhere, but every compute call raises without the 
 """
 from ._lib import G16Error, Context, ProvingKey, PointSet, VerifyingKey, lib_path, load_library  # noqa: F401
 from .msm import (msmMultiThreadedG1, msmMultiThreadedG2, msmG1, msmG2)  # noqa: F401
-from .ntt import Domain, createDomain, forwardNTT, inverseNTT  # noqa: F401
-from .prover import (Proof, Mask, Witness, generateProof, generateProofWithMask,  # noqa: F401
+from .ntt import (Domain, createDomain, forwardNTT, inverseNTT, extendAndForwardNTT,  # noqa: F401
+                  polyForwardNTT, polyInverseNTT)
+from .prover import (ABC, Proof, Mask, Witness, buildABC, computeQuotientPointwise,  # noqa: F401
+                     computeSnarkjsScalarCoeffs, generateProof, generateProofWithMask,
                      generateProofWithTrivialMask, loadProvingKey)
 from .verifier import VKey, extractVKey, loadVerifyingKey, verifyProof, verifyProofs  # noqa: F401
 from .zkey_types import ZKey, GrothHeader, SpecPoints, ProverPoints, JensGroth, Snarkjs  # noqa: F401

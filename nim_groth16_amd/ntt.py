@@ -44,3 +44,16 @@ def extendAndForwardNTT(src: bytes, D: Domain, ctx=None) -> bytes:
     n = len(src) // 32
     assert n <= D.domainSize
     return forwardNTT(src + b"\x00" * (32 * (D.domainSize - n)), D, ctx)
+
+
+def polyForwardNTT(coeffs: bytes, D: Domain, ctx=None) -> bytes:
+    """poly.nim:255-260 -- a Poly's coefficients (seq[Fr] bytes) evaluated on the domain.  The reference asserts
+    `coeffs.len <= domainSize` and then calls forwardNTT, which needs equality; here shorter polynomials are padded,
+    which is what the assert intends."""
+    assert len(coeffs) // 32 <= D.domainSize, "the input polynomial must have at most `domainSize` coefficients"
+    return extendAndForwardNTT(coeffs, D, ctx)
+
+
+def polyInverseNTT(ys: bytes, D: Domain, ctx=None) -> bytes:
+    """poly.nim:264-268 -- values on the domain -> coefficients"""
+    return inverseNTT(ys, D, ctx)

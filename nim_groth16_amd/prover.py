@@ -10,7 +10,7 @@ from typing import Optional
 
 from . import bn128 as F
 from ._lib import PkeyDesc, ProvingKey, default_context
-from .zkey_types import ZKey, packCoeffs
+from .zkey_types import JensGroth, Snarkjs, ZKey, packCoeffs
 
 
 @dataclass
@@ -68,6 +68,38 @@ def _pkey_for(zkey: ZKey, ctx) -> ProvingKey:
     if key not in _pkey_cache:
         _pkey_cache[key] = (zkey, loadProvingKey(zkey, ctx))
     return _pkey_cache[key][1]
+
+
+@dataclass
+class ABC:                           # prover.nim:49-53
+    valuesAz: bytes
+    valuesBz: bytes
+    valuesCz: bytes
+
+
+def buildABC(zkey: ZKey, witness: bytes, ctx=None, pkey: Optional[ProvingKey] = None) -> ABC:
+    """prover.nim:56-73 -- A*z, B*z and their pointwise product on the domain (sparse mat-vec on the GPU);
+    witness = nvars Fr in the Nim seq[Fr] layout"""
+    ctx = ctx or default_context()
+    assert zkey.header.nvars * 32 == len(witness), "wrong witness length"
+    a, b, c = (pkey or _pkey_for(zkey, ctx)).build_abc(witness)
+    return ABC(a, b, c)
+
+
+def _log2n(abc: ABC) -> int:
+    n = len(abc.valuesAz) // 32
+    assert len(abc.valuesBz) == len(abc.valuesCz) == 32 * n and n & (n - 1) == 0 and n > 0   # prover.nim:160-161
+    return n.bit_length() - 1
+
+
+def computeSnarkjsScalarCoeffs(nthreads: int, abc: ABC, ctx=None) -> bytes:
+    """prover.nim:158-181 -- the H-MSM scalars of a snarkjs-flavour key (6 NTTs + pointwise, on the GPU)"""
+    return (ctx or default_context()).quotient(abc.valuesAz, abc.valuesBz, abc.valuesCz, _log2n(abc), Snarkjs)
+
+
+def computeQuotientPointwise(nthreads: int, abc: ABC, ctx=None) -> bytes:
+    """prover.nim:118-148 -- coefficients of the quotient polynomial (JensGroth flavour, 7 NTTs)"""
+    return (ctx or default_context()).quotient(abc.valuesAz, abc.valuesBz, abc.valuesCz, _log2n(abc), JensGroth)
 
 
 def generateProofWithMask(nthreads: int, printTimings: bool, zkey: ZKey, wtns: Witness, mask: Mask,

@@ -283,3 +283,25 @@ def test_zkey_point_check_on_gpu(ctx, tmp_path):
     writeZKey(path, bad)
     with pytest.raises(AssertionError):
         parseZKey(path, check=True, ctx=ctx)
+
+
+def test_named_path_functions_mirror_the_reference(ctx):
+    """buildABC / computeSnarkjsScalarCoeffs / computeQuotientPointwise / polyForwardNTT / polyInverseNTT under the
+    reference's names (prover.nim:56-181, poly.nim:255-268), on the toy circuit, against the oracle"""
+    from nim_groth16_amd import (ABC, buildABC, computeQuotientPointwise, computeSnarkjsScalarCoeffs, createDomain,
+                                 polyForwardNTT, polyInverseNTT)
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    a, b, g, d, t = _toxic(5)
+    toy = o.toy_r1cs()
+    zk = fakeCircuitSetup(R1CS(8, 1, 1, 3, toy.constraints), ToxicWaste(a, b, g, d, t), 1, ctx)
+    abc = buildABC(zk, I.fr_mont_bytes(o.TOY_WITNESS), ctx)
+    Az, Bz, Cz = o.build_abc(o.r1cs_to_coeffs(toy), 8, o.TOY_WITNESS)
+    assert isinstance(abc, ABC)
+    assert (I.fr_from_mont(abc.valuesAz), I.fr_from_mont(abc.valuesBz), I.fr_from_mont(abc.valuesCz)) == (Az, Bz, Cz)
+    assert I.fr_from_mont(computeSnarkjsScalarCoeffs(0, abc, ctx)) == o.compute_snarkjs_scalar_coeffs(Az, Bz, Cz)
+    assert I.fr_from_mont(computeQuotientPointwise(0, abc, ctx)) == o.compute_quotient_pointwise(Az, Bz, Cz)
+    D = createDomain(16)
+    coeffs = I.uniform_scalars(11, 41)                       # shorter than the domain: padded (poly.nim:257-259)
+    ys = polyForwardNTT(I.fr_mont_bytes(coeffs), D, ctx)
+    assert I.fr_from_mont(ys) == o.forward_ntt(coeffs + [0] * 5, o.Domain(16))
+    assert I.fr_from_mont(polyInverseNTT(ys, D, ctx)) == coeffs + [0] * 5
