@@ -52,6 +52,10 @@ static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
   // keeps most buckets in one segment, the rest get 1-2 short extra segments that msm_reduce1 absorbs.
   size_t avg = ((size_t)n * P.nwin) / P.nbuckets + 1;
   P.seg = (uint32_t)(((avg + avg / 4 + 15) / 16) * 16);
+  // few, long buckets (small windows / small point sets): cut them so that the launch still has ~64 k tasks --
+  // a task is a serial chain, and 2^11 buckets of 1500 entries each would otherwise run as 2^11 threads
+  const size_t cap = (((size_t)n * P.nwin / 65536 + 15) / 16) * 16;
+  if (P.seg > cap) P.seg = (uint32_t)cap;
   if (P.seg < 32) P.seg = 32;
   if (const char* env = getenv("G16_MSM_SEG")) {
     int v = atoi(env);
