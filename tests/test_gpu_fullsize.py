@@ -65,6 +65,21 @@ def test_ntt_fullsize_roundtrip_linearity_and_direct_evaluation(ctx):
         assert (a + b) % R == c
 
 
+@pytest.mark.parametrize("log2n", [21, 22, 24])
+def test_ntt_large_domains_roundtrip(ctx, log2n):
+    """domains beyond the benchmark size (config 4 uses 2^22; the library accepts up to 2^27): round trip and
+    y_0 = sum x_i (the Montgomery encoding is linear, so the sum can be taken on the raw limbs)"""
+    import numpy as np
+    n = 1 << log2n
+    raw = np.random.default_rng(log2n).integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= (1 << 59) - 1                                 # < 2^251 < r: valid residues
+    xb = raw.astype("<u8").tobytes()
+    yb = ctx.ntt(xb, log2n, False)
+    assert ctx.ntt(yb, log2n, True) == xb
+    s = sum(int(raw[:, j].astype(object).sum()) << (64 * j) for j in range(4))
+    assert int.from_bytes(yb[:32], "little") == s % R
+
+
 def test_full_proof_2p16_bit_exact_vs_c_oracle_and_2p18_verifies(ctx, orc):
     from nim_groth16_amd import (Mask, Witness, extractVKey, generateProofWithMask, loadProvingKey, verifyProof)
     from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
