@@ -172,14 +172,27 @@ struct Ec29<G2> {
   template <uint32_t KM>
   static FF_HD f2e29 f2mul(const f2e29& a, const f2e29& b) {
     fe29 n1 = F::negk<KM, 1>(a.c1);
+#if defined(G16_F29_PAIR)
+    f2e29 r;
+    F::dot_pair<2>(r.c0, r.c1, a.c0, b.c0, n1, b.c1, n1, n1, n1, n1, a.c0, b.c1, a.c1, b.c0, n1, n1, n1, n1);
+    return r;
+#else
     return f2e29{F::dot2(a.c0, b.c0, n1, b.c1), F::dot2(a.c0, b.c1, a.c1, b.c0)};
+#endif
   }
   // ((a0+a1)(a0-a1), 2 a0 a1)
   template <uint32_t KM>
   static FF_HD f2e29 f2sqr(const f2e29& a) {
     fe29 s = F::add(a.c0, a.c1);
     fe29 d = F::subk<KM, 1>(a.c0, a.c1);
+#if defined(G16_F29_PAIR)
+    fe29 t = F::add(a.c0, a.c0);
+    f2e29 r;
+    F::dot_pair<1>(r.c0, r.c1, s, d, s, s, s, s, s, s, t, a.c1, s, s, s, s, s, s);
+    return r;
+#else
     return f2e29{F::mul(s, d), F::mul(F::add(a.c0, a.c0), a.c1)};
+#endif
   }
 
   using Tab = g2_tab29;
@@ -252,8 +265,14 @@ struct Ec29<G2> {
     fe29 nr1 = F::norm(F::negk<8, 1>(nR.c1));
     fe29 ny0 = F::norm(F::negk<4, 1>(acc.y.c0));
     fe29 ny1 = F::norm(F::negk<4, 1>(acc.y.c1));
+#if defined(G16_F29_PAIR)
+    f2e29 y3;
+    F::dot_pair<4>(y3.c0, y3.c1, nR.c0, d.c0, nr1, d.c1, ny0, ppp.c0, acc.y.c1, ppp.c1,
+                   nR.c0, d.c1, nR.c1, d.c0, ny0, ppp.c1, ny1, ppp.c0);
+#else
     f2e29 y3{F::dot4(nR.c0, d.c0, nr1, d.c1, ny0, ppp.c0, acc.y.c1, ppp.c1),
              F::dot4(nR.c0, d.c1, nR.c1, d.c0, ny0, ppp.c1, ny1, ppp.c0)};
+#endif
     acc.x = x3;
     acc.y = y3;
   }

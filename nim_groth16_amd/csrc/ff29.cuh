@@ -23,9 +23,10 @@
 // compiler starts each column from zero (shorter critical path, which 4 waves/SIMD do not need) and joins it with
 // the carry through an extra 64-bit add per column (144 v_lshl_add_u64 per mixed addition).  The asm costs an
 // s_nop each (hazard padding), still a net win where occupancy hides the longer chain: msm_accum_g1 (4 waves/SIMD)
-// 1.007 -> 0.956 ms; the G2 accumulate (2 waves/SIMD) and the reduce kernels (1 wave/SIMD) get slower, so only
-// msm_g1_accum.hip is built with -DG16_F29_SERIAL (Makefile).  (A *volatile* asm orders all field operations
-// against each other and made the kernel 3x slower.)
+// 1.007 -> 0.956 ms.  At 2 waves/SIMD (G2 accumulate) one serial chain per wave stalls, so that kernel computes its
+// Fp2 products as two interleaved pinned chains (dot_pair, -DG16_F29_PAIR): 2.83 -> 2.69 ms.  The reduce kernels
+// (1 wave/SIMD) get slower with pins; only the two accumulate translation units are built with -DG16_F29_SERIAL
+// (Makefile).  (A *volatile* asm orders all field operations against each other and made the kernel 3x slower.)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(G16_F29_SERIAL)
 #define F29_MAC(acc, a, b)              \
   do {                                  \
@@ -133,6 +134,51 @@ struct Fp29 {
     }
     r.v[L - 1] = (uint32_t)acc;
     return r;
+  }
+  // two independent NP-term dot products column by column in lockstep (r0 = sum a_j*b_j, r1 = sum c_j*d_j): with
+  // the serial pins of F29_MAC each result is one multiply-add chain without join adds, and the two chains give
+  // a wave the instruction-level parallelism that a single serial chain lacks at 2 waves/SIMD (G2 kernels)
+  template <int NP>
+  static FF_HD void dot_pair(fe29& r0, fe29& r1, const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1,
+                             const fe29& a2, const fe29& b2, const fe29& a3, const fe29& b3, const fe29& c0,
+                             const fe29& d0, const fe29& c1, const fe29& d1, const fe29& c2, const fe29& d2,
+                             const fe29& c3, const fe29& d3) {
+    uint32_t m[L], n[L];
+    uint64_t acc = 0, bcc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; ++k) {
+      const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) {
+        F29_MAC(acc, a0.v[i], b0.v[k - i]);
+        F29_MAC(bcc, c0.v[i], d0.v[k - i]);
+        if constexpr (NP > 1) F29_MAC(acc, a1.v[i], b1.v[k - i]);
+        if constexpr (NP > 1) F29_MAC(bcc, c1.v[i], d1.v[k - i]);
+        if constexpr (NP > 2) F29_MAC(acc, a2.v[i], b2.v[k - i]);
+        if constexpr (NP > 2) F29_MAC(bcc, c2.v[i], d2.v[k - i]);
+        if constexpr (NP > 3) F29_MAC(acc, a3.v[i], b3.v[k - i]);
+        if constexpr (NP > 3) F29_MAC(bcc, c3.v[i], d3.v[k - i]);
+      }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i)
+        if (!(k < L && i == k)) {
+          F29_MAC(acc, m[i], PL.v[k - i]);
+          F29_MAC(bcc, n[i], PL.v[k - i]);
+        }
+      if (k < L) {
+        m[k] = ((uint32_t)acc * N0) & MASK;
+        n[k] = ((uint32_t)bcc * N0) & MASK;
+        F29_MAC(acc, m[k], PL.v[0]);
+        F29_MAC(bcc, n[k], PL.v[0]);
+      } else {
+        r0.v[k - L] = (uint32_t)acc & MASK;
+        r1.v[k - L] = (uint32_t)bcc & MASK;
+      }
+      acc >>= B;
+      bcc >>= B;
+    }
+    r0.v[L - 1] = (uint32_t)acc;
+    r1.v[L - 1] = (uint32_t)bcc;
   }
   static FF_HD fe29 mul(const fe29& a, const fe29& b) { return dot<1>(a, b, a, b, a, b, a, b); }
   static FF_HD fe29 dot2(const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1) {

@@ -24,6 +24,19 @@ def shim():
     return ctypes.CDLL(so)
 
 
+@pytest.fixture(scope="module")
+def shim_pair():
+    """the same shim built with -DG16_F29_PAIR: the Fp2 products of ec29.cuh go through Fp29::dot_pair (the G2
+    accumulate kernel's configuration)"""
+    so = os.path.join(HERE, "libffec_shim_pair.so")
+    src = os.path.join(HERE, "ffec_shim.cpp")
+    import glob
+    deps = [src] + glob.glob(os.path.join(HERE, "..", "..", "nim_groth16_amd", "csrc", "*.cuh"))
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DG16_F29_PAIR", "-shared", "-fPIC", src, "-o", so])
+    return ctypes.CDLL(so)
+
+
 def test_field_formulas(shim):
     rng = random.Random(1)
     for field, mod in ((0, o.P), (1, o.R)):
@@ -128,6 +141,23 @@ def test_reduced_radix_accumulate(shim, group):
         assert gsum(0, pts) == exp
         assert gsum(1, pts) == exp
         assert gsum(2, pts) == exp      # pairwise tree of general XYZZ + XYZZ additions (bucket reduction)
+
+
+def test_reduced_radix_accumulate_g2_with_chain_pairs(shim_pair):
+    """G2 mixed additions with the interleaved dot-product pairs (Fp29::dot_pair) of the G2 accumulate build"""
+    rng = random.Random(6)
+    P1, P2, P3 = (o.G2.mul(rng.randrange(o.R), o.GEN2) for _ in range(3))
+    pool = [o.G2.mul(rng.randrange(o.R), o.GEN2) for _ in range(6)]
+    cases = [[P1, P2, P3], [P1, P1], [P1, o.G2.neg(P1)], [o.G2.inf, P1, o.G2.inf, P2], [P1] * 5,
+             [rng.choice(pool + [o.G2.inf]) if rng.random() < 0.8 else o.G2.neg(rng.choice(pool)) for _ in range(150)]]
+    for pts in cases:
+        exp = o.G2.inf
+        for q in pts:
+            exp = o.G2.add(exp, q)
+        for op in (0, 1):
+            r = ctypes.create_string_buffer(128)
+            shim_pair.shim_g2_sum29(op, b"".join(o.g2_to_bytes(p) for p in pts), len(pts), r)
+            assert o.g2_from_bytes(r.raw) == exp
 
 
 def test_reduced_radix_interval_model():
