@@ -18,7 +18,11 @@
  * Error convention: every function returns 0 on success or a negative G16_E* code; nothing
  * throws or aborts across the boundary (the reference uses `assert`, msm.nim:97, ntt.nim:56-57).
  * A g16_ctx is used by one host thread at a time; distinct contexts are independent.
+ * Registered point sets, proving keys and verification keys (g16_points / g16_pkey / g16_vkey) are immutable and
+ * belong to the DEVICE of the context that created them: any context of that device may use them, concurrently
+ * (the in-flight proofs of one GPU share one resident key), and they may be released before or after any context.
  * Inputs are read-only and not retained after return, except explicitly registered point sets.
+ * G16_* environment knobs are read once per process, at the first g16_ctx_create.
  * There is NO CPU fallback: without a usable HIP device every call fails with G16_ENODEV.
  */
 #ifndef G16HIP_H
@@ -196,10 +200,14 @@ int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* key, const void* witness, ui
  * Proof.publicIO (prover.nim:238-240); flags: G16_SCALARS_MONT / G16_SCALARS_STD for the scalars, and
  * G16_VERIFY_SUBGROUP to also require [r]pi_b = infinity (the reference only asserts the curve equations).
  * status[j]: 1 = proof j verifies, 0 = pairing equation fails, -1 / -2 / -3 = pi_a / pi_b / pi_c is not on its
- * curve (the reference's three asserts), -4 = pi_b is not in the order-r subgroup.
+ * curve (the reference's three asserts), -4 = pi_b is not in the order-r subgroup, -5 = a proof coordinate is not
+ * the canonical residue (limbs >= p), -6 = a public input is not canonical (>= r): each proof / input has exactly
+ * one accepted byte encoding.  (The smallest code wins when several apply.)
  * g16_pairing: out_gt[i] = e(P_i, Q_i) as 6 x Fp2 = 384 bytes, coefficient k of w^k in
  * Fp12 = Fp2[w]/(w^6 - (9+u)) (the tower of files/export_sage.nim:84-97 flattened), Montgomery form;
- * e is the ate pairing f_{t-1,Q}(P)^((p^12-1)/r). */
+ * e is the ate pairing f_{t-1,Q}(P)^((p^12-1)/r).  NOT byte-compatible with the GT values of the reference's
+ * `pairing` (constantine's optimal ate, curves.nim:218-221): the two differ by a fixed exponent, so products /
+ * equality-to-one tests (all verifyProof needs) agree, the 384 bytes do not. */
 typedef struct g16_vkey g16_vkey;
 typedef struct {
   uint32_t npubs;

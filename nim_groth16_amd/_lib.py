@@ -152,12 +152,15 @@ class Context:
             raise G16Error(rc, "g16_ctx_create failed (no usable HIP device?)")
         self._h = h
         self.device = device
-        self._children = weakref.WeakSet()   # point sets / proving keys that must die before the context
+        # point sets / keys created through this context.  They belong to the DEVICE (include/g16hip.h): the C ABI
+        # lets them outlive the context or die first, in any order; the set only serves close(release_children=True)
+        self._children = weakref.WeakSet()
 
-    def close(self):
+    def close(self, release_children: bool = False):
         if getattr(self, "_h", None):
-            for child in list(self._children):
-                child._free()
+            if release_children:
+                for child in list(self._children):
+                    child._free()
             self._lib.g16_ctx_destroy(self._h)
             self._h = None
 
@@ -290,44 +293,48 @@ class ProvingKey:
         ctx._children.add(self)
         del keepalive
 
-    def prove(self, witness, mont: bool = True, r: bytes = None, s: bytes = None, device: bool = False):
+    # Every call takes an optional `ctx`: the key is a per-DEVICE constant, and any context of its device may
+    # prove against it -- several proofs in flight on one GPU = several contexts (private streams + workspaces)
+    # sharing ONE resident key.  Default: the context the key was created through.
+    def prove(self, witness, mont: bool = True, r: bytes = None, s: bytes = None, device: bool = False, ctx=None):
         """-> (pi_a 64 B, pi_b 128 B, pi_c 64 B); r, s: Fr Montgomery bytes or None (trivial mask)."""
+        c = ctx or self.ctx
         out = ctypes.create_string_buffer(256)
         flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
-        self.ctx._check(self.ctx._lib.g16_prove(self.ctx._h, self._h, _buf(witness), flags,
-                                                _buf(r) if r else None, _buf(s) if s else None, out))
+        c._check(c._lib.g16_prove(c._h, self._h, _buf(witness), flags, _buf(r) if r else None,
+                                  _buf(s) if s else None, out))
         raw = out.raw
         return raw[0:64], raw[64:192], raw[192:256]
 
-    def prove_partials(self, witness, mont: bool = True, device: bool = False, out=None):
+    def prove_partials(self, witness, mont: bool = True, device: bool = False, out=None, ctx=None):
         """this rank's five XYZZ MSM partials (768 bytes); out = device pointer to write them into HBM."""
+        c = ctx or self.ctx
         flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
         if out is not None:
-            self.ctx._check(self.ctx._lib.g16_prove_partials(self.ctx._h, self._h, _buf(witness), flags | OUT_DEVICE,
-                                                             _buf(out)))
+            c._check(c._lib.g16_prove_partials(c._h, self._h, _buf(witness), flags | OUT_DEVICE, _buf(out)))
             return None
         buf = ctypes.create_string_buffer(PARTIALS_BYTES)
-        self.ctx._check(self.ctx._lib.g16_prove_partials(self.ctx._h, self._h, _buf(witness), flags, buf))
+        c._check(c._lib.g16_prove_partials(c._h, self._h, _buf(witness), flags, buf))
         return buf.raw
 
-    def prove_combine(self, partials, count: int, r: bytes = None, s: bytes = None, device: bool = False):
+    def prove_combine(self, partials, count: int, r: bytes = None, s: bytes = None, device: bool = False, ctx=None):
+        c = ctx or self.ctx
         out = ctypes.create_string_buffer(256)
-        self.ctx._check(self.ctx._lib.g16_prove_combine(self.ctx._h, self._h, _buf(partials), count,
-                                                        SCALARS_DEVICE if device else 0,
-                                                        _buf(r) if r else None, _buf(s) if s else None, out))
+        c._check(c._lib.g16_prove_combine(c._h, self._h, _buf(partials), count, SCALARS_DEVICE if device else 0,
+                                          _buf(r) if r else None, _buf(s) if s else None, out))
         raw = out.raw
         return raw[0:64], raw[64:192], raw[192:256]
 
-    def build_abc(self, witness: bytes, mont: bool = True):
+    def build_abc(self, witness: bytes, mont: bool = True, ctx=None):
+        c = ctx or self.ctx
         n = 1 << self.log2n
         out = ctypes.create_string_buffer(3 * n * 32)
-        self.ctx._check(self.ctx._lib.g16_build_abc(self.ctx._h, self._h, _buf(witness),
-                                                    SCALARS_MONT if mont else 0, out))
+        c._check(c._lib.g16_build_abc(c._h, self._h, _buf(witness), SCALARS_MONT if mont else 0, out))
         raw = out.raw
         return raw[: 32 * n], raw[32 * n: 64 * n], raw[64 * n:]
 
     def _free(self):
-        if self._h and self.ctx._h:
+        if self._h:                      # valid whether or not the creating context is still alive
             self.ctx._lib.g16_pkey_destroy(self._h)
         self._h = None
 
@@ -371,7 +378,7 @@ class VerifyingKey:
         return list(st)[:n]
 
     def _free(self):
-        if self._h and self.ctx._h:
+        if self._h:
             self.ctx._lib.g16_vkey_destroy(self._h)
         self._h = None
 
@@ -398,7 +405,7 @@ class PointSet:
         return c.value, w.value
 
     def _free(self):
-        if self._h and self.ctx._h:
+        if self._h:
             self.ctx._lib.g16_points_release(self._h)
         self._h = None
 

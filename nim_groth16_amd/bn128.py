@@ -36,6 +36,11 @@ def frSeqToMontBytes(xs) -> bytes:
     return b"".join(frToMontBytes(x) for x in xs)
 
 
+def frSeqToStdBytes(xs) -> bytes:
+    """the .wtns layout (files/witness.nim:14): canonical little-endian, not Montgomery"""
+    return b"".join((x % primeR).to_bytes(32, "little") for x in xs)
+
+
 def frSeqFromMontBytes(buf: bytes):
     return [frFromMontBytes(buf[i:i + 32]) for i in range(0, len(buf), 32)]
 

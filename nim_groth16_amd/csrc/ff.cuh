@@ -432,6 +432,14 @@ struct Field {
     for (int i = 0; i < 8; ++i) t.v[i] = subc(a.v[i], b.v[i], bw);
     return bw == 0;
   }
+  static FF_HD T modulus() {
+    T m;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m.v[i] = Pi(i);
+    return m;
+  }
+  // a < modulus: the only encoding of a residue this library produces and (at the verifier) accepts
+  static FF_HD bool is_canonical(const T& a) { return !geq(a, modulus()); }
   static FF_HD T raw_sub(const T& a, const T& b) {
     T t;
     uint32_t bw = 0;

@@ -13,6 +13,19 @@
 
 #include "msm_params.hpp"
 
+// Experiment knobs (G16_* environment variables), read ONCE per process -- at the first g16_ctx_create -- and never
+// again on the per-proof path.  0 / '\0' = not set.
+struct G16Env {
+  int msm_window = 0;      // G16_MSM_WINDOW   5..22: window bits of the one-shot MSMs
+  int table_window = 0;    // G16_TABLE_WINDOW 5..22: window bits of registered point sets
+  int msm_seg = 0;         // G16_MSM_SEG      8..4096: accumulate segment length
+  char msm_sort = 0;       // G16_MSM_SORT     'a': atomic histogram/scatter instead of the partition sort
+  int g1_lanes[3] = {0, 2, 3};   // G16_G1_LANES  lanes of the A1 / B1 / C1 MSMs (three digits from {0,2,3})
+  char stream_prio[7] = "lhllln";   // G16_STREAM_PRIO  six characters from {h, n, l}
+  int red_slice_log2 = 0;  // G16_RED_SLICE    log2 of the chunks per reduce2 slice of a merged bucket set (8..11)
+};
+const G16Env& g16_env();
+
 struct ProfEntry {
   const char* name;
   hipEvent_t e0, e1;
@@ -79,10 +92,19 @@ struct g16_ctx {
     }                                                                                          \
   } while (0)
 
+// waits for everything this context has queued: the main stream AND the five MSM lane streams.  Called before a
+// workspace buffer is freed or regrown, on every error exit of a multi-stream launch sequence and at teardown, so
+// that no lane kernel can still be reading a buffer that is about to go away.
+inline void ctx_quiesce(g16_ctx* ctx) {
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& l : ctx->lane)
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+}
+
 inline int32_t ensure(g16_ctx* ctx, g16_ctx::Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return G16_OK;
   if (b.p) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx_quiesce(ctx);
     HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
@@ -169,9 +191,11 @@ int32_t g16_fixed_base_device_g1(g16_ctx* ctx, void* d_table, bool ready, const 
 int32_t g16_fixed_base_device_g2(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
                                  void* d_out);
 
-// device-resident point set with precomputed window tables
+// device-resident point set with precomputed window tables.  Immutable after registration and tied to a DEVICE,
+// not to the context that created it: every context of that device may run MSMs against it concurrently (the
+// in-flight proofs of one GPU share one key), and it may be released before or after any context.
 struct g16_points {
-  g16_ctx* ctx = nullptr;
+  int device = 0;
   int group = 1;          // 1: G1 (64-byte points), 2: G2 (128-byte points)
   size_t n = 0;
   uint32_t c = 0, nwin = 0;

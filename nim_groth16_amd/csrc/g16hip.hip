@@ -5,10 +5,37 @@
 
 using namespace g16;
 
+// ---- environment knobs: parsed once ----------------------------------------------------------------
+static G16Env read_env() {
+  G16Env e;
+  auto num = [](const char* name, int lo, int hi) {
+    const char* v = getenv(name);
+    if (!v) return 0;
+    int x = atoi(v);
+    return x >= lo && x <= hi ? x : 0;
+  };
+  e.msm_window = num("G16_MSM_WINDOW", 5, 22);
+  e.table_window = num("G16_TABLE_WINDOW", 5, 22);
+  e.msm_seg = num("G16_MSM_SEG", 8, 4096);
+  e.red_slice_log2 = num("G16_RED_SLICE", 8, 11);
+  if (const char* v = getenv("G16_MSM_SORT")) e.msm_sort = v[0];
+  if (const char* v = getenv("G16_G1_LANES"))
+    if (strlen(v) == 3 && strspn(v, "023") == 3)
+      for (int i = 0; i < 3; ++i) e.g1_lanes[i] = v[i] - '0';
+  if (const char* v = getenv("G16_STREAM_PRIO"))
+    if (strlen(v) >= 6 && strspn(v, "hnl") >= 6) memcpy(e.stream_prio, v, 6);
+  return e;
+}
+const G16Env& g16_env() {
+  static const G16Env env = read_env();   // thread-safe one-time initialisation
+  return env;
+}
+
 // ---- context ------------------------------------------------------------------------------------
 extern "C" int32_t g16_ctx_create(int32_t device, g16_ctx** out) {
   if (!out) return G16_EINVAL;
   *out = nullptr;
+  (void)g16_env();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return G16_ENODEV;
   if (device < 0 || device >= ndev) return G16_EINVAL;
@@ -33,12 +60,11 @@ extern "C" int32_t g16_ctx_create(int32_t device, g16_ctx** out) {
 // (buildABC, quotient NTTs, H).  Default "lhllln" (G2 high, main normal, G1 lanes low): the G2 MSM has the longest
 // latency chain of a proof; prioritising it lets its reduce/fold tail overlap the G1 accumulations of this and
 // of the other in-flight proofs (measured with 3 proofs in flight: 78 proofs/s flat, 90 "lhlllh", 97 "lhllln").
-// G16_STREAM_PRIO = six characters from {h, n, l} overrides it.
+// G16_STREAM_PRIO = six characters from {h, n, l} overrides it (read once per process, g16_env).
 int g16_stream_priority(int index) {
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // numerically: hi <= lo
-  const char* cfg = getenv("G16_STREAM_PRIO");
-  if (!cfg || strlen(cfg) < 6) cfg = "lhllln";
+  const char* cfg = g16_env().stream_prio;
   switch (cfg[index]) {
     case 'h': return hi;
     case 'l': return lo;
@@ -61,12 +87,9 @@ int32_t g16_lanes_init(g16_ctx* ctx) {
 extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  ctx_quiesce(ctx);
   for (auto& l : ctx->lane) {
-    if (l.stream) {
-      (void)hipStreamSynchronize(l.stream);
-      (void)hipStreamDestroy(l.stream);
-    }
+    if (l.stream) (void)hipStreamDestroy(l.stream);
     if (l.done) (void)hipEventDestroy(l.done);
     if (l.acc.p) (void)hipFree(l.acc.p);
   }
@@ -207,7 +230,7 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
   HIPCHK(ctx, hipSetDevice(ctx->device));
   g16_points* h = new (std::nothrow) g16_points();
   if (!h) return G16_ENOMEM;
-  h->ctx = ctx;
+  h->device = ctx->device;
   h->group = group;
   h->n = n;
   h->c = g16_pick_window_g1(n);
@@ -262,8 +285,10 @@ extern "C" int32_t g16_points_register_g2_dev(g16_ctx* ctx, const void* d_points
 extern "C" void g16_points_release(g16_points* h) {
   if (!h) return;
   if (h->d_tables) {
-    (void)hipSetDevice(h->ctx->device);
-    (void)hipStreamSynchronize(h->ctx->stream);
+    // any context of the device may still have an MSM against these tables in flight, and the context that
+    // registered them may already be gone: wait for the whole device, never for one context's stream
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
     (void)hipFree(h->d_tables);
   }
   delete h;
@@ -343,8 +368,8 @@ extern "C" int32_t g16_fixed_base_g2(g16_ctx* ctx, const void* scalars, uint32_t
 extern "C" int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const void* scalars, uint32_t flags,
                                   void* out) {
   if (!ctx) return G16_EINVAL;
-  if (!pts || !out || pts->ctx != ctx || (pts->n && !scalars)) {
-    ctx->err = "bad argument (null pointer or point set of another context)";
+  if (!pts || !out || pts->device != ctx->device || (pts->n && !scalars)) {
+    ctx->err = "bad argument (null pointer or point set of another device)";
     return G16_EINVAL;
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));

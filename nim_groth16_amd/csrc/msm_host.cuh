@@ -17,11 +17,8 @@ static uint32_t floor_log2(size_t x) {
 // with precomputed 2^(c w) tables (`merged`).  A short top window (t = 254 - (nwin-1) c bits) would map all n
 // scalars onto 2^t buckets, so candidates need t >= min(c-2, 6).  2^20 points: c = 16 plain, c = 20 merged
 // (13 tables instead of 16 windows).
-static uint32_t pick_window_cost(size_t n, bool merged, const char* env_name, uint32_t cmax) {
-  if (const char* env = getenv(env_name)) {
-    int v = atoi(env);
-    if (v >= 5 && v <= 22) return (uint32_t)v;
-  }
+static uint32_t pick_window_cost(size_t n, bool merged, int forced, uint32_t cmax) {
+  if (forced) return (uint32_t)forced;   // G16_MSM_WINDOW / G16_TABLE_WINDOW (g16_env: read once per process)
   uint32_t best = 5;
   double best_cost = 1e300;
   for (uint32_t c = 5; c <= cmax; ++c) {
@@ -38,7 +35,7 @@ static uint32_t pick_window_cost(size_t n, bool merged, const char* env_name, ui
   }
   return best;
 }
-static uint32_t pick_window(size_t n) { return pick_window_cost(n ? n : 1, false, "G16_MSM_WINDOW", 16); }
+static uint32_t pick_window(size_t n) { return pick_window_cost(n ? n : 1, false, g16_env().msm_window, 16); }
 
 static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
   MsmParams P;
@@ -57,10 +54,7 @@ static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
   const size_t cap = (((size_t)n * P.nwin / 65536 + 15) / 16) * 16;
   if (P.seg > cap) P.seg = (uint32_t)cap;
   if (P.seg < 32) P.seg = 32;
-  if (const char* env = getenv("G16_MSM_SEG")) {
-    int v = atoi(env);
-    if (v >= 8 && v <= 4096) P.seg = (uint32_t)v;
-  }
+  if (g16_env().msm_seg) P.seg = (uint32_t)g16_env().msm_seg;
   P.scalars_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
   P.max_extra = (uint32_t)(((size_t)P.n * P.nwin) / P.seg + 1);
   return P;
@@ -87,8 +81,7 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   const uint32_t lo_bits = P.c - 1 < 8 ? P.c - 1 : 8;
   const uint32_t nparts = P.nbuckets >> lo_bits;
   const uint32_t ptiles = (P.n + PART_TILE - 1) / PART_TILE;
-  const char* env_sort = getenv("G16_MSM_SORT");
-  const bool use_part = nparts <= PART_MAX && !(env_sort && env_sort[0] == 'a');
+  const bool use_part = nparts <= PART_MAX && g16_env().msm_sort != 'a';
   const size_t nth = (size_t)nparts * ptiles;
   const size_t o_thist = take(use_part ? nth * 4 : 4), o_tmp = take(use_part ? (size_t)P.n * P.nwin * 8 : 8),
                o_tiles2 = take(((nth + SCAN_TILE - 1) / SCAN_TILE) * 8 + 8),
@@ -150,5 +143,5 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   return G16_OK;
 }
 
-static uint32_t pick_table_window(size_t n) { return pick_window_cost(n ? n : 1, true, "G16_TABLE_WINDOW", 22); }
+static uint32_t pick_table_window(size_t n) { return pick_window_cost(n ? n : 1, true, g16_env().table_window, 22); }
 

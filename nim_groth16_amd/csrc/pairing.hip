@@ -7,7 +7,7 @@
 using namespace g16;
 
 struct g16_vkey {
-  g16_ctx* ctx = nullptr;
+  int device = 0;
   uint32_t npubs = 0;
   g2_aff gamma2, delta2;
   void* d_ic = nullptr;   // (npubs + 1) G1 points
@@ -50,10 +50,12 @@ __device__ bool on_curve_g2(const g2_aff& p, const fp2_t& b) {
 // partial[j * (npubs+1) + i] = publicIO[j][i] * IC[i]
 __global__ void __launch_bounds__(PBLOCK) verify_pub_terms(const u256* __restrict__ pub, uint32_t mont,
                                                            const g1_aff* __restrict__ ic, uint32_t nio,
-                                                           uint32_t total, g1_acc* __restrict__ partial) {
+                                                           uint32_t total, g1_acc* __restrict__ partial,
+                                                           int32_t* __restrict__ status) {
   uint32_t t = blockIdx.x * PBLOCK + threadIdx.x;
   if (t >= total) return;
   u256 s = pub[t];
+  if (!Fr::is_canonical(s)) atomicMin(&status[t / nio], -6);   // one public input, one accepted encoding
   if (mont) s = Fr::from_mont(s);
   partial[t] = scalar_mul<G1>(ic[t % nio], s);
 }
@@ -73,6 +75,11 @@ __global__ void __launch_bounds__(PBLOCK) verify_miller(const g16_proof* __restr
   if (which == 0) {
     P = *reinterpret_cast<const g1_aff*>(pr.pi_a);
     Q = *reinterpret_cast<const g2_aff*>(pr.pi_b);
+    // every coordinate must be the canonical residue (< p): the field arithmetic below would silently reduce a
+    // larger limb pattern, so without this one proof would have several accepted byte encodings
+    if (!Fp::is_canonical(P.x) || !Fp::is_canonical(P.y) || !Fp::is_canonical(Q.x.c0) || !Fp::is_canonical(Q.x.c1) ||
+        !Fp::is_canonical(Q.y.c0) || !Fp::is_canonical(Q.y.c1))
+      atomicMin(&status[j], -5);
     if (!on_curve_g1(P)) atomicMin(&status[j], -1);
     if (!on_curve_g2(Q, twist_b)) {
       atomicMin(&status[j], -2);
@@ -85,6 +92,7 @@ __global__ void __launch_bounds__(PBLOCK) verify_miller(const g16_proof* __restr
   } else if (which == 1) {
     P = *reinterpret_cast<const g1_aff*>(pr.pi_c);
     Q = delta2;
+    if (!Fp::is_canonical(P.x) || !Fp::is_canonical(P.y)) atomicMin(&status[j], -5);
     if (!on_curve_g1(P)) atomicMin(&status[j], -3);
   } else {
     g1_acc acc = G1::acc_inf();
@@ -166,7 +174,7 @@ extern "C" int32_t g16_vkey_create(g16_ctx* ctx, const g16_vkey_desc* d, g16_vke
   HIPCHK(ctx, hipSetDevice(ctx->device));
   g16_vkey* k = new (std::nothrow) g16_vkey();
   if (!k) return G16_ENOMEM;
-  k->ctx = ctx;
+  k->device = ctx->device;
   k->npubs = d->npubs;
   memcpy(&k->gamma2, d->gamma2, 128);
   memcpy(&k->delta2, d->delta2, 128);
@@ -199,7 +207,8 @@ extern "C" int32_t g16_vkey_create(g16_ctx* ctx, const g16_vkey_desc* d, g16_vke
 
 extern "C" void g16_vkey_destroy(g16_vkey* k) {
   if (!k) return;
-  if (k->ctx) (void)hipSetDevice(k->ctx->device);
+  (void)hipSetDevice(k->device);   // device-bound like g16_pkey: valid before and after any context
+  (void)hipDeviceSynchronize();
   if (k->d_ic) (void)hipFree(k->d_ic);
   if (k->d_ab) (void)hipFree(k->d_ab);
   delete k;
@@ -208,7 +217,7 @@ extern "C" void g16_vkey_destroy(g16_vkey* k) {
 extern "C" int32_t g16_verify(g16_ctx* ctx, const g16_vkey* key, const g16_proof* proofs, const void* public_io,
                               uint32_t flags, size_t count, int32_t* status) {
   if (!ctx) return G16_EINVAL;
-  if (!key || key->ctx != ctx || (count && (!proofs || !public_io || !status)) || count >= (size_t(1) << 22)) {
+  if (!key || key->device != ctx->device || (count && (!proofs || !public_io || !status)) || count >= (size_t(1) << 22)) {
     ctx->err = "g16_verify: bad arguments";
     return G16_EINVAL;
   }
@@ -231,7 +240,7 @@ extern "C" int32_t g16_verify(g16_ctx* ctx, const g16_vkey* key, const g16_proof
   HIPCHK(ctx, hipMemsetAsync(ws + o_st, 0, count * 4, ctx->stream));
   KLAUNCH(ctx, "verify_pub_terms", verify_pub_terms, (uint32_t)((total + PBLOCK - 1) / PBLOCK), PBLOCK, 0,
           (const u256*)(ws + o_pub), (flags & G16_SCALARS_MONT) ? 1u : 0u, (const g1_aff*)key->d_ic, (uint32_t)nio,
-          (uint32_t)total, (g1_acc*)(ws + o_part));
+          (uint32_t)total, (g1_acc*)(ws + o_part), (int32_t*)(ws + o_st));
   KLAUNCH(ctx, "verify_miller", verify_miller, (uint32_t)((3 * count + PBLOCK - 1) / PBLOCK), PBLOCK, 0,
           (const g16_proof*)(ws + o_pr), (uint32_t)count, (const g1_acc*)(ws + o_part), (uint32_t)nio, key->gamma2,
           key->delta2, twist_b(), (flags & G16_VERIFY_SUBGROUP) ? 1u : 0u, (fp12_t*)(ws + o_mil),

@@ -15,8 +15,11 @@
 
 using namespace g16;
 
+// Immutable after g16_pkey_create and tied to a DEVICE, not to the creating context: the in-flight proofs of one
+// GPU (one g16_ctx each: private streams and workspaces) all prove against ONE resident key, and the key may be
+// destroyed before or after any of those contexts (ProverPoints are per-circuit constants, zkey_types.nim:36-41).
 struct g16_pkey {
-  g16_ctx* ctx = nullptr;
+  int device = 0;
   uint32_t nvars = 0, npubs = 0, log2n = 0, flavour = 1;
   // this key holds the index ranges [lo, hi) of each point set (msm.nim:105-115 chunk rule over shard_count ranks)
   uint32_t shard_index = 0, shard_count = 1;
@@ -102,10 +105,9 @@ static DevAff host_add(const DevAff& a_dev, const DevAff& b_dev) {
 extern "C" void g16_pkey_destroy(g16_pkey* k) {
   if (!k) return;
   for (g16_points* p : {k->A1, k->B1, k->B2, k->C1, k->H1}) g16_points_release(p);
-  if (k->ctx) {
-    (void)hipSetDevice(k->ctx->device);
-    (void)hipStreamSynchronize(k->ctx->stream);
-  }
+  // like g16_points_release: wait for the device, not for a context (the creating one may be gone already)
+  (void)hipSetDevice(k->device);
+  (void)hipDeviceSynchronize();
   if (k->d_rowptr) (void)hipFree(k->d_rowptr);
   if (k->d_col) (void)hipFree(k->d_col);
   if (k->d_val) (void)hipFree(k->d_val);
@@ -130,7 +132,7 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
   HIPCHK(ctx, hipSetDevice(ctx->device));
   g16_pkey* k = new (std::nothrow) g16_pkey();
   if (!k) return G16_ENOMEM;
-  k->ctx = ctx;
+  k->device = ctx->device;
   k->nvars = d->nvars;
   k->npubs = d->npubs;
   k->log2n = d->log2_domain;
@@ -228,7 +230,7 @@ static int32_t build_abc_device(g16_ctx* ctx, const g16_pkey* k, const u256* d_w
 
 extern "C" int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, void* out_abc) {
   if (!ctx) return G16_EINVAL;
-  if (!k || !witness || !out_abc || k->ctx != ctx) {
+  if (!k || !witness || !out_abc || k->device != ctx->device) {
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
@@ -249,14 +251,27 @@ extern "C" int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* k, const void* wi
 //   [0,128) A1 | [128,256) B1 | [256,512) B2 (G2) | [512,640) H1 | [640,768) C1
 static constexpr size_t PART_A = 0, PART_B1 = 128, PART_B2 = 256, PART_H = 512, PART_C = 640, PART_BYTES = 768;
 
+static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
+                                   void* out_partials);
+
 extern "C" int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
                                       void* out_partials) {
   if (!ctx) return G16_EINVAL;
-  if (!k || !witness || !out_partials || k->ctx != ctx) {
+  if (!k || !witness || !out_partials || k->device != ctx->device) {
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int32_t rc = prove_partials_impl(ctx, k, witness, flags, out_partials);
+  // an error exit may leave work queued on the lane streams (e.g. a failed allocation after the witness MSMs were
+  // launched): drain all of them before returning, so that the caller -- or the next call's ensure() -- can never
+  // free a buffer a lane kernel is still reading
+  if (rc != G16_OK) ctx_quiesce(ctx);
+  return rc;
+}
+
+static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
+                                   void* out_partials) {
   const size_t n = size_t(1) << k->log2n;
   const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
   int32_t rc;
@@ -285,10 +300,8 @@ extern "C" int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* k, const voi
     for (int i = 1; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, ctx->ev_b, 0));
     if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, ctx->sort[0], k->B2->d_tables, nullptr, slots + PART_B2)))
       return rc;
-    // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES = three digits from {0, 2, 3} (experiments)
-    int la = 0, lb = 2, lc = 3;
-    if (const char* e = getenv("G16_G1_LANES"))
-      if (strlen(e) == 3 && strspn(e, "023") == 3) la = e[0] - '0', lb = e[1] - '0', lc = e[2] - '0';
+    // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES (read once per process, g16_env) reassigns them
+    const int la = g16_env().g1_lanes[0], lb = g16_env().g1_lanes[1], lc = g16_env().g1_lanes[2];
     if ((rc = g16_msm_reduce_g1(ctx, L[la].stream, L[la].acc, ctx->sort[0], k->A1->d_tables, nullptr, slots + PART_A)))
       return rc;
     if ((rc = g16_msm_reduce_g1(ctx, L[lb].stream, L[lb].acc, ctx->sort[0], k->B1->d_tables, nullptr, slots + PART_B1)))
@@ -336,7 +349,7 @@ static __global__ void prove_combine_kernel(const unsigned char* __restrict__ ga
 extern "C" int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* k, const void* partials, size_t count,
                                      uint32_t flags, const void* mask_r, const void* mask_s, g16_proof* out) {
   if (!ctx) return G16_EINVAL;
-  if (!k || !partials || !out || k->ctx != ctx || count == 0 || count > 1024) {
+  if (!k || !partials || !out || k->device != ctx->device || count == 0 || count > 1024) {
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
@@ -388,7 +401,7 @@ extern "C" int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* k, const void
 extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, const void* mask_r,
                              const void* mask_s, g16_proof* out) {
   if (!ctx) return G16_EINVAL;
-  if (!k || !witness || !out || k->ctx != ctx) {
+  if (!k || !witness || !out || k->device != ctx->device) {
     ctx->err = "bad argument";
     return G16_EINVAL;
   }

@@ -44,7 +44,10 @@ class ShardedProver:
         on_gpu = self.pkey is not None
         if on_gpu:
             mine = torch.empty(PARTIALS_BYTES, dtype=torch.uint8, device=f"cuda:{self.pkey.ctx.device}")
-            self.pkey.prove_partials(wtns.values, mont=True, out=mine.data_ptr())
+            # a parsed .wtns is standard form (files/witness.nim:14), a Nim seq[Fr] is Montgomery
+            self.pkey.prove_partials(wtns.values, mont=not wtns.std, out=mine.data_ptr())
+            if self.group_is_cpu():
+                mine = mine.cpu()               # gloo rehearsal on a one-GPU box: the exchange runs on the host
         else:
             mine = torch.frombuffer(bytearray(self.partials_fn(wtns.values)), dtype=torch.uint8)
         gathered = torch.empty(self.world * PARTIALS_BYTES, dtype=torch.uint8, device=mine.device)
@@ -52,9 +55,20 @@ class ShardedProver:
             self.dist.all_gather_into_tensor(gathered, mine, group=self.group)   # the one exchange per proof
         else:
             gathered.copy_(mine)
-        if on_gpu:
-            torch.cuda.current_stream(mine.device).synchronize()
+        if on_gpu and gathered.is_cuda:
+            torch.cuda.current_stream(gathered.device).synchronize()
             pi_a, pi_b, pi_c = self.pkey.prove_combine(gathered.data_ptr(), self.world, r, s, device=True)
+        elif on_gpu:
+            pi_a, pi_b, pi_c = self.pkey.prove_combine(bytes(gathered.numpy()), self.world, r, s)
         else:
             pi_a, pi_b, pi_c = self.combine_fn(bytes(gathered.numpy()), self.world, r, s)
-        return Proof(wtns.values[: 32 * (hdr.npubs + 1)], pi_a, pi_b, pi_c)
+        pubIO = wtns.values[: 32 * (hdr.npubs + 1)]
+        if wtns.std:                     # Proof.publicIO is seq[Fr]: Montgomery in memory (as prover.py:115-118)
+            pubIO = F.frSeqToMontBytes(int.from_bytes(pubIO[i:i + 32], "little") for i in range(0, len(pubIO), 32))
+        return Proof(pubIO, pi_a, pi_b, pi_c)
+
+    def group_is_cpu(self) -> bool:
+        """True when the process group cannot move CUDA tensors (backend gloo)"""
+        if self.world <= 1 or not self.dist.is_initialized():
+            return False
+        return "nccl" not in str(self.dist.get_backend(self.group)).lower()

@@ -40,7 +40,9 @@ def loadVerifyingKey(vkey: VKey, ctx: Context = None) -> VerifyingKey:
 
 
 _ASSERTS = {-1: "pi_a is not in G1", -2: "pi_b is not in G2", -3: "pi_c is not in G1",
-            -4: "pi_b is not in the order-r subgroup of G2"}
+            -4: "pi_b is not in the order-r subgroup of G2",
+            -5: "a proof coordinate is not a canonical field element (>= p)",
+            -6: "a public input is not a canonical scalar (>= r)"}
 
 
 def verifyProofs(vkey, proofs: Sequence[Proof], ctx: Context = None, subgroup: bool = False) -> List[bool]:

@@ -384,6 +384,65 @@ static void* shift_eval_thread(void* arg) {
   free(tmp);
   return NULL;
 }
+/* the three shiftEvalDomain tasks both quotient flavours start with (prover.nim:132-138, 167-173); v[k] malloc'ed */
+static int shift_eval_abc(const void* Az, const void* Bz, const void* Cz, int log2n, int parallel, fe* v[3]);
+
+/* computeQuotientPointwise (prover.nim:118-148), JensGroth flavour: coefficients of Q = (A*B - C) / Z */
+int orc_quotient_jensgroth(const void* Az, const void* Bz, const void* Cz, int log2n, void* out, int parallel) {
+  size_t n = (size_t)1 << log2n;
+  fe* v[3];
+  int rc = shift_eval_abc(Az, Bz, Cz, log2n, parallel, v);
+  if (rc) return rc;
+  /* invZ1 = 1 / (eta^n - 1), eta = createDomain(2n).domainGen   (prover.nim:127-128) */
+  fe eta, etan, zm1, invZ1, eta_inv;
+  domain_gen(&eta, log2n + 1);
+  etan = eta;
+  for (int k = 0; k < log2n; ++k) fe_sqr(&etan, &etan, &MR);   /* smallPowFr(eta, n), n = 2^log2n */
+  fe_sub(&zm1, &etan, &MR.one, &MR);
+  fe_inv(&invZ1, &zm1, &MR);
+  fe* ys = (fe*)malloc(n * sizeof(fe));
+  if (!ys) return -1;
+  for (size_t j = 0; j < n; ++j) {   /* prover.nim:141 */
+    fe p, d;
+    fe_mul(&p, &v[0][j], &v[1][j], &MR);
+    fe_sub(&d, &p, &v[2][j], &MR);
+    fe_mul(&ys[j], &d, &invZ1, &MR);
+  }
+  fe* o = (fe*)out;
+  rc = orc_ntt_inverse(ys, o, log2n);   /* prover.nim:142 */
+  fe_inv(&eta_inv, &eta, &MR);
+  fe pw = MR.one;
+  for (size_t i = 0; i < n; ++i) {      /* multiplyByPowers(Q1.coeffs, invFr(eta)), prover.nim:143 */
+    fe_mul(&o[i], &o[i], &pw, &MR);
+    fe_mul(&pw, &pw, &eta_inv, &MR);
+  }
+  free(ys);
+  for (int k = 0; k < 3; ++k) free(v[k]);
+  return rc;
+}
+
+static int shift_eval_abc(const void* Az, const void* Bz, const void* Cz, int log2n, int parallel, fe* v[3]) {
+  size_t n = (size_t)1 << log2n;
+  const void* in[3] = {Az, Bz, Cz};
+  shift_task t[3];
+  pthread_t th[3];
+  for (int k = 0; k < 3; ++k) {
+    v[k] = (fe*)malloc(n * sizeof(fe));
+    if (!v[k]) return -1;
+    memcpy(v[k], in[k], n * sizeof(fe));
+    t[k].v = v[k];
+    t[k].log2n = log2n;
+    t[k].rc = 0;
+  }
+  if (parallel) {
+    for (int k = 0; k < 3; ++k) pthread_create(&th[k], NULL, shift_eval_thread, &t[k]);
+    for (int k = 0; k < 3; ++k) pthread_join(th[k], NULL);
+  } else {
+    for (int k = 0; k < 3; ++k) shift_eval_thread(&t[k]);
+  }
+  return t[0].rc | t[1].rc | t[2].rc;
+}
+
 /* computeSnarkjsScalarCoeffs (prover.nim:158-181): 3 tasks, then A1*B1 - C1 */
 int orc_quotient_snarkjs(const void* Az, const void* Bz, const void* Cz, int log2n, void* out, int parallel) {
   size_t n = (size_t)1 << log2n;

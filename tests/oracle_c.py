@@ -23,6 +23,7 @@ class Oracle:
         lib.orc_ntt_forward.argtypes = [vp, vp, i32]
         lib.orc_ntt_inverse.argtypes = [vp, vp, i32]
         lib.orc_quotient_snarkjs.argtypes = [vp, vp, vp, i32, vp, i32]
+        lib.orc_quotient_jensgroth.argtypes = [vp, vp, vp, i32, vp, i32]
         lib.orc_build_abc.argtypes = [vp, sz, vp, i32, vp]
 
     @staticmethod
@@ -72,6 +73,13 @@ class Oracle:
     def quotient_snarkjs(self, Az: bytes, Bz: bytes, Cz: bytes, log2n: int, parallel=True) -> bytes:
         out = ctypes.create_string_buffer(len(Az))
         rc = self.lib.orc_quotient_snarkjs(Az, Bz, Cz, log2n, out, 1 if parallel else 0)
+        assert rc == 0
+        return out.raw
+
+    def quotient_jensgroth(self, Az: bytes, Bz: bytes, Cz: bytes, log2n: int, parallel=True) -> bytes:
+        """computeQuotientPointwise (prover.nim:118-148)"""
+        out = ctypes.create_string_buffer(len(Az))
+        rc = self.lib.orc_quotient_jensgroth(Az, Bz, Cz, log2n, out, 1 if parallel else 0)
         assert rc == 0
         return out.raw
 

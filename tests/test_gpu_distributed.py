@@ -1,0 +1,80 @@
+"""The GPU branch of ShardedProver under a real 2-rank process group on the one-GPU box: both ranks compute their
+g16_prove_partials / g16_prove_combine on device 0 with sharded keys (msm.nim:105-115 ranges), the 768-byte records
+travel through a gloo all-gather, and every rank must end with the proof of the unsharded key, which is in turn
+held to the C oracle.  Domain 2^16: the per-shard window choice and table sizes are the real ones."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+LOG2N = 16
+
+
+def _inputs():
+    from nim_groth16_amd.synthetic import SplitMix64, squaringChain
+    m = (1 << LOG2N) - 2
+    r1cs, wit = squaringChain(m, seed=4)
+    rng = SplitMix64(5)
+    tox = [rng.fr() for _ in range(5)]
+    return r1cs, wit, tox, (rng.fr(), rng.fr())
+
+
+def _rank(rank, world, port, q):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nim_groth16_amd import Context, Mask, Witness
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd.distributed import ShardedProver
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    r1cs, wit, tox, (r, s) = _inputs()
+    ctx = Context(0)                                   # both ranks share the box's single GPU
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(*tox), 1, ctx)
+    sp = ShardedProver(zk, rank, world, ctx=ctx)       # partials_fn=None: the real sharded key on the GPU
+    assert sp.pkey is not None and sp.group_is_cpu()
+    out = []
+    for std in (False, True):
+        vals = F.frSeqToStdBytes(wit) if std else F.frSeqToMontBytes(wit)
+        pr = sp.prove(Witness("bn128", len(wit), vals, std=std), Mask(r, s))
+        out.append((pr.pi_a, pr.pi_b, pr.pi_c, pr.publicIO))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+    sp.pkey.destroy()
+    ctx.close()
+
+
+@pytest.mark.timeout(900)
+def test_sharded_prover_gpu_branch_world2_gloo(ctx, orc):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=800) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # reference: the unsharded key in this process, itself bit-exact against the C oracle
+    from nim_groth16_amd import Mask, Witness, generateProofWithMask, loadProvingKey
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from tests.parity import check_gpu_proof
+    r1cs, wit, tox, (r, s) = _inputs()
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(*tox), 1, ctx)
+    pk = loadProvingKey(zk, ctx)
+    wb = F.frSeqToMontBytes(wit)
+    want = generateProofWithMask(0, False, zk, Witness("bn128", len(wit), wb), Mask(r, s), ctx, pkey=pk)
+    check_gpu_proof(orc, zk, wit, wb, r, s, (want.pi_a, want.pi_b, want.pi_c), ctx)
+    for rank in (0, 1):
+        for got in outs[rank]:                          # Montgomery and standard-form witness
+            assert got == (want.pi_a, want.pi_b, want.pi_c, want.publicIO), rank
+    pk.destroy()

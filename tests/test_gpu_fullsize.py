@@ -20,27 +20,35 @@ def _bytes(vals):
     return F.frSeqToMontBytes(vals)
 
 
-@pytest.mark.parametrize("group,log2n", [(1, 20), (2, 18)])
-def test_msm_fullsize_known_discrete_logs(ctx, group, log2n):
-    """P_i = k_i * G (fixed-base kernel), so that sum s_i P_i = (sum s_i k_i mod r) * G  (SURVEY 8d config 2 check)"""
+@pytest.mark.parametrize("group,log2n", [(1, 20), (2, 18), (2, 20)])
+def test_msm_fullsize_known_discrete_logs(ctx, orc, group, log2n):
+    """P_i = k_i * G, so that sum s_i P_i = (sum s_i k_i mod r) * G  (SURVEY 8d config 2 check).  The point set is
+    produced by the product's fixed-base kernel (the oracle would take minutes at 2^20); the EXPECTED value is the
+    oracle's own scalar multiplication of the generator, so the check does not loop back into the product -- and a
+    wrong point set could not cancel out: a sample of it is held to the oracle's fixed-base multiplier too."""
     n = 1 << log2n
     ks, sc = _stream(1, n), _stream(2, n)
     sc[5] = 0
     sc[7] = sc[6]                                  # a zero scalar and a repeated one
     pts = ctx.fixed_base(group, _bytes(ks))
     psz = 64 * group
+    sample = [0, 1, 2, 12345 % n, n // 2, n - 1]
+    assert b"".join(pts[psz * i:psz * (i + 1)] for i in sample) == orc.fixed_base(group, _bytes([ks[i] for i in sample]))
     pts = pts[:psz * 9] + bytes(psz) + pts[psz * 10:]            # an infinity point inside the set
     ks[9] = 0
     e = sum(s * k for s, k in zip(sc, ks)) % R
-    exp = ctx.fixed_base(group, _bytes([e]))
+    gen = o.g1_to_bytes(o.GEN1) if group == 1 else o.g2_to_bytes(o.GEN2)
+    exp = orc.mul(group, _bytes([e]), gen)                       # oracle, not ctx.fixed_base
+    assert exp == orc.fixed_base(group, _bytes([e]))
     sb = _bytes(sc)
-    assert ctx.msm(group, sb, pts, n) == exp
+    if log2n < 20 or group == 1:
+        assert ctx.msm(group, sb, pts, n) == exp                 # one-shot path (no tables)
     h = ctx.register_points(group, pts, n)
     try:
         assert ctx.msm_points(h, sb) == exp
         # linearity in the scalars: MSM(2 s) == 2 MSM(s)
         two = ctx.msm_points(h, _bytes([2 * s % R for s in sc]))
-        assert two == ctx.fixed_base(group, _bytes([2 * e % R]))
+        assert two == orc.mul(group, _bytes([2 * e % R]), gen)
     finally:
         h.release()
 
@@ -80,37 +88,38 @@ def test_ntt_large_domains_roundtrip(ctx, log2n):
     assert int.from_bytes(yb[:32], "little") == s % R
 
 
-def test_full_proof_2p16_bit_exact_vs_c_oracle_and_2p18_verifies(ctx, orc):
+def _prove_and_check(ctx, orc, log2n, bit_exact, flavour=1):
     from nim_groth16_amd import (Mask, Witness, extractVKey, generateProofWithMask, loadProvingKey, verifyProof)
     from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
     from nim_groth16_amd.synthetic import SplitMix64, squaringChain
-    from nim_groth16_amd.zkey_types import packCoeffs
-    for log2n in (16, 18):
-        m = (1 << log2n) - 2
-        r1cs, wit = squaringChain(m, seed=4)
-        rng = SplitMix64(5)
-        zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
-        pk = loadProvingKey(zk, ctx)
+    from tests.parity import check_gpu_proof
+    m = (1 << log2n) - 2
+    r1cs, wit = squaringChain(m, seed=4)
+    rng = SplitMix64(5)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), flavour, ctx)
+    pk = loadProvingKey(zk, ctx)
+    try:
         wb = _bytes(wit)
         mask = Mask(rng.fr(), rng.fr())
         pr = generateProofWithMask(0, False, zk, Witness("bn128", m + 2, wb), mask, ctx, pkey=pk)
         assert verifyProof(extractVKey(zk), pr, ctx)                          # testProver.nim:65-73 at scale
-        if log2n == 16:   # the five MSMs and the quotient recomputed by the C oracle, then the O(1) mask algebra
-            pts, hdr = zk.pPoints, zk.header
-            Az, Bz, Cz = orc.build_abc(packCoeffs(zk.coeffs), wb, log2n)
-            qs = orc.quotient_snarkjs(Az, Bz, Cz, log2n)
-            it = iter([o.g1_from_bytes(orc.msm(1, wb, pts.pointsA1)), o.g1_from_bytes(orc.msm(1, wb, pts.pointsB1)),
-                       o.g2_from_bytes(orc.msm(2, wb, pts.pointsB2)), o.g1_from_bytes(orc.msm(1, qs, pts.pointsH1)),
-                       o.g1_from_bytes(orc.msm(1, wb[32 * (hdr.npubs + 1):], pts.pointsC1))])
-            oz = o.ZKey()
-            oz.flavour, oz.nvars, oz.npubs, oz.domainSize = o.SNARKJS, hdr.nvars, hdr.npubs, hdr.domainSize
-            sp = zk.specPoints
-            oz.alpha1, oz.beta1, oz.delta1 = (o.g1_from_bytes(x) for x in (sp.alpha1, sp.beta1, sp.delta1))
-            oz.beta2, oz.gamma2, oz.delta2 = (o.g2_from_bytes(x) for x in (sp.beta2, sp.gamma2, sp.delta2))
-            oz.pointsA1 = oz.pointsB1 = oz.pointsB2 = [None] * hdr.nvars
-            oz.pointsC1, oz.pointsH1, oz.coeffs = [None] * (hdr.nvars - hdr.npubs - 1), [None] * hdr.domainSize, []
-            ref = o.generate_proof_with_mask(oz, wit, mask.r, mask.s, msm_g1=lambda c_, p_: next(it),
-                                             msm_g2=lambda c_, p_: next(it), quotient=lambda *a: [0] * hdr.domainSize)
-            assert (o.g1_from_bytes(pr.pi_a), o.g2_from_bytes(pr.pi_b), o.g1_from_bytes(pr.pi_c)) == \
-                (ref.pi_a, ref.pi_b, ref.pi_c)
+        if bit_exact:   # buildABC, the H scalars and the five MSMs recomputed by the C oracle, then the mask algebra
+            check_gpu_proof(orc, zk, wit, wb, mask.r, mask.s, (pr.pi_a, pr.pi_b, pr.pi_c), ctx)
+    finally:
         pk.destroy()
+
+
+def test_full_proof_2p16_bit_exact_vs_c_oracle_and_2p18_verifies(ctx, orc):
+    _prove_and_check(ctx, orc, 16, True)
+    _prove_and_check(ctx, orc, 18, False)
+
+
+def test_full_proof_2p14_jensgroth_bit_exact_vs_c_oracle(ctx, orc):
+    """the JensGroth flavour (7 NTTs, prover.nim:118-148) beyond the toy size, against the C oracle"""
+    _prove_and_check(ctx, orc, 14, True, flavour=0)
+
+
+def test_full_proof_2p20_bit_exact_vs_c_oracle(ctx, orc):
+    """BASELINE config 3 (2^20-constraint circuit, full prove) inside the suite: bit-exact against the C oracle's
+    proof and accepted by both verifiers -- the same check that gates every bench.py run (tests/parity.py)."""
+    _prove_and_check(ctx, orc, 20, True)

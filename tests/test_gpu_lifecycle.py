@@ -1,0 +1,137 @@
+"""Object lifetime and sharing rules of the C ABI (include/g16hip.h): registered point sets and keys belong to the
+device, not to the context that created them -- any teardown order is legal, and the in-flight proofs of one GPU
+share one resident key (ProverPoints are per-circuit constants, reference groth16/zkey_types.nim:36-41)."""
+import subprocess
+import sys
+import threading
+
+import pytest
+
+from oracle import bn254_ref as o
+from tests import inputs as I
+
+pytestmark = pytest.mark.gpu
+
+_TEARDOWN = r"""
+import ctypes, sys
+sys.path.insert(0, {root!r})
+from nim_groth16_amd import Context, loadProvingKey
+from nim_groth16_amd._lib import load_library
+from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+from nim_groth16_amd.synthetic import SplitMix64, squaringChain
+lib = load_library()
+ctx = Context(0)
+r1cs, wit = squaringChain((1 << 7) - 2, seed=4)
+rng = SplitMix64(5)
+zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
+pk = loadProvingKey(zk, ctx)
+hs = ctx.register_points(1, zk.pPoints.pointsA1, zk.header.nvars)
+from nim_groth16_amd import bn128 as F
+proof = pk.prove(F.frSeqToMontBytes(wit))
+# the order the C ABI must survive: context first, THEN its key and point set (raw handles, no Python guard)
+lib.g16_ctx_destroy(ctx._h); ctx._h = None
+lib.g16_pkey_destroy(pk._h); pk._h = None
+lib.g16_points_release(hs._h); hs._h = None
+# and the key of a dead context's device is still usable from a NEW context of that device
+ctx2 = Context(0)
+pk2 = loadProvingKey(zk, ctx2)
+ctx3 = Context(0)
+assert pk2.prove(F.frSeqToMontBytes(wit), ctx=ctx3) == proof
+ctx2.close()                      # creating context gone, key alive and in use through ctx3
+assert pk2.prove(F.frSeqToMontBytes(wit), ctx=ctx3) == proof
+pk2.destroy(); ctx3.close()
+print("teardown ok")
+"""
+
+
+def test_teardown_in_any_order_exits_cleanly():
+    """g16_ctx_destroy with live g16_pkey / g16_points, then destroying those, must not abort (round-1 core dump at
+    interpreter exit: the key's destroy touched its dead context's stream)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TEARDOWN.format(root=root)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "teardown ok" in r.stdout
+
+
+def test_one_key_shared_by_concurrent_contexts(ctx, orc):
+    """three contexts (private streams + workspaces) prove three DIFFERENT witnesses against ONE resident key from
+    three host threads at once; every proof equals the one the creating context produces alone"""
+    from nim_groth16_amd import Context, loadProvingKey
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import SplitMix64, squaringChain
+    m = (1 << 12) - 2
+    r1cs, wit0 = squaringChain(m, seed=4)
+    wits = [wit0] + [squaringChain(m, seed=4, w0=w0)[1] for w0 in (5, 7)]     # same circuit, other satisfying inputs
+    rng = SplitMix64(5)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
+    pk = loadProvingKey(zk, ctx)
+    r, s = F.frToMontBytes(rng.fr()), F.frToMontBytes(rng.fr())
+    wbs = [F.frSeqToMontBytes(w) for w in wits]
+    alone = [pk.prove(wb, r=r, s=s) for wb in wbs]
+    assert len(set(alone)) == 3
+    others = [Context(0) for _ in range(3)]
+    got = [[None] * 4 for _ in range(3)]
+
+    def work(i):
+        for rep in range(4):
+            got[i][rep] = pk.prove(wbs[i], r=r, s=s, ctx=others[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(3):
+        assert got[i] == [alone[i]] * 4
+    with pytest.raises(Exception):
+        pk.prove(wbs[0][:-32], ctx=others[0])        # wrong length is still refused by the host mirror / ABI
+    for c in others:
+        c.close()
+    pk.destroy()
+
+
+def test_sharded_prover_takes_a_parsed_standard_form_witness(ctx, tmp_path):
+    """ShardedProver (world 1, real GPU halves) on a parseWitness() witness -- standard form on disk,
+    files/witness.nim:14 -- equals generateProofWithMask, incl. the Montgomery publicIO of Proof (prover.nim:238-240)"""
+    from nim_groth16_amd import Mask, generateProofWithMask
+    from nim_groth16_amd.distributed import ShardedProver
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.files import parseWitness, writeWitness
+    rng = o.SplitMix64(61)
+    tox = ToxicWaste(*[rng.fr() for _ in range(5)])
+    zk = fakeCircuitSetup(R1CS(8, 1, 1, 3, o.toy_r1cs().constraints), tox, 1, ctx)
+    wpath = str(tmp_path / "toy.wtns")
+    writeWitness(wpath, o.TOY_WITNESS)
+    wt = parseWitness(wpath)
+    assert wt.std
+    mask = Mask(rng.fr(), rng.fr())
+    want = generateProofWithMask(0, False, zk, wt, mask, ctx)
+    got = ShardedProver(zk, 0, 1, ctx=ctx).prove(wt, mask)
+    assert (got.pi_a, got.pi_b, got.pi_c, got.publicIO) == (want.pi_a, want.pi_b, want.pi_c, want.publicIO)
+    assert I.fr_from_mont(got.publicIO) == [1, 2023, 1022]
+
+
+def test_verifier_rejects_non_canonical_encodings(ctx):
+    """one proof, one accepted byte encoding: coordinates >= p and public inputs >= r are refused (-5 / -6), not
+    silently reduced"""
+    from nim_groth16_amd import extractVKey, loadVerifyingKey
+    from tests.test_gpu_verifier import _toy
+    zk, (good, _) = _toy(ctx)
+    dev = loadVerifyingKey(extractVKey(zk), ctx)
+    tri = (good.pi_a, good.pi_b, good.pi_c)
+    assert dev.verify([tri], good.publicIO) == [1]
+
+    def plus(buf, off, mod):
+        v = int.from_bytes(buf[off:off + 32], "little") + mod
+        assert v < 1 << 256
+        return buf[:off] + v.to_bytes(32, "little") + buf[off + 32:]
+    for which, off in ((0, 0), (0, 32), (1, 0), (1, 96), (2, 32)):
+        t = list(tri)
+        t[which] = plus(t[which], off, o.P)                       # same residue, non-canonical limbs
+        assert dev.verify([tuple(t)], good.publicIO) == [-5], (which, off)
+    assert dev.verify([tri], plus(good.publicIO, 32, o.R)) == [-6]
+    assert dev.verify([tri, tri], good.publicIO + plus(good.publicIO, 64, o.R)) == [1, -6]
+    std = I.fr_std_bytes(I.fr_from_mont(good.publicIO))
+    assert dev.verify([tri], std, mont=False) == [1]
+    assert dev.verify([tri], plus(std, 32, o.R), mont=False) == [-6]

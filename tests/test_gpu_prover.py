@@ -68,14 +68,16 @@ def test_toy_circuit_setup_prove_verify_bit_exact(ctx, flavour):
         assert o.verify_proof(oz, ref)                      # verifier.nim:31-52
 
 
-@pytest.mark.parametrize("log2n", [1, 3, 8, 11, 14])
+@pytest.mark.parametrize("log2n", [1, 3, 8, 11, 14, 17])
 @pytest.mark.parametrize("flavour", [0, 1])
 def test_quotient_vs_oracle(ctx, orc, log2n, flavour):
     n = 1 << log2n
     A, B, C = (I.uniform_scalars(n, s) for s in (21, 22, 23))
     got = ctx.quotient(I.fr_mont_bytes(A), I.fr_mont_bytes(B), I.fr_mont_bytes(C), log2n, flavour)
-    if flavour == 1:
-        assert got == orc.quotient_snarkjs(I.fr_mont_bytes(A), I.fr_mont_bytes(B), I.fr_mont_bytes(C), log2n)
+    ab, bb, cb = I.fr_mont_bytes(A), I.fr_mont_bytes(B), I.fr_mont_bytes(C)
+    # every (flavour, size) pair is held to the C oracle; the small ones also to the Python transliteration
+    assert got == (orc.quotient_snarkjs(ab, bb, cb, log2n) if flavour == 1 else
+                   orc.quotient_jensgroth(ab, bb, cb, log2n))
     if log2n <= 8:
         exp = o.compute_snarkjs_scalar_coeffs(A, B, C) if flavour else o.compute_quotient_pointwise(A, B, C)
         assert I.fr_from_mont(got) == exp

@@ -59,6 +59,24 @@ def test_ntt_and_quotient(orc, lg):
         A, B, Cc = (I.uniform_scalars(n, s) for s in (1, 2, 3))
         q = orc.quotient_snarkjs(*(I.fr_mont_bytes(v) for v in (A, B, Cc)), lg)
         assert I.fr_from_mont(q) == o.compute_snarkjs_scalar_coeffs(A, B, Cc)
+        # JensGroth flavour (computeQuotientPointwise, prover.nim:118-148), serial and 3-task
+        for par in (False, True):
+            qj = orc.quotient_jensgroth(*(I.fr_mont_bytes(v) for v in (A, B, Cc)), lg, parallel=par)
+            assert I.fr_from_mont(qj) == o.compute_quotient_pointwise(A, B, Cc)
+
+
+def test_quotient_jensgroth_is_the_quotient_polynomial(orc):
+    """size-independent pin of the C JensGroth quotient at a mid size: for Az, Bz, Cz = Az*Bz on the domain
+    (what buildABC produces, prover.nim:56-73) the output q satisfies q(x) * (x^n - 1) == A(x)*B(x) - C(x) at
+    random points x, with A, B, C the interpolants (the defining property of prover.nim:116-117)."""
+    lg, n = 10, 1 << 10
+    A, B = I.uniform_scalars(n, 51), I.uniform_scalars(n, 52)
+    Cc = [a * b % o.R for a, b in zip(A, B)]
+    q = I.fr_from_mont(orc.quotient_jensgroth(*(I.fr_mont_bytes(v) for v in (A, B, Cc)), lg))
+    ca, cb, cc = (I.fr_from_mont(orc.ntt(I.fr_mont_bytes(v), lg, inverse=True)) for v in (A, B, Cc))
+    ev = lambda cs, x: sum(c * pow(x, i, o.R) for i, c in enumerate(cs)) % o.R     # noqa: E731
+    for x in I.uniform_scalars(3, 53):
+        assert ev(q, x) * (pow(x, n, o.R) - 1) % o.R == (ev(ca, x) * ev(cb, x) - ev(cc, x)) % o.R
 
 
 def test_domain_generator(orc):
