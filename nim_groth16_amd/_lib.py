@@ -296,9 +296,16 @@ class ProvingKey:
     # Every call takes an optional `ctx`: the key is a per-DEVICE constant, and any context of its device may
     # prove against it -- several proofs in flight on one GPU = several contexts (private streams + workspaces)
     # sharing ONE resident key.  Default: the context the key was created through.
+    def _check_len(self, witness):
+        # the C ABI takes a bare pointer and reads nvars * 32 bytes: refuse a short host buffer here
+        # (generateProofWithMask's "wrong witness length", prover.nim:236)
+        if isinstance(witness, (bytes, bytearray)) and len(witness) != 32 * self.nvars:
+            raise ValueError(f"wrong witness length: {len(witness)} bytes, expected {32 * self.nvars}")
+
     def prove(self, witness, mont: bool = True, r: bytes = None, s: bytes = None, device: bool = False, ctx=None):
         """-> (pi_a 64 B, pi_b 128 B, pi_c 64 B); r, s: Fr Montgomery bytes or None (trivial mask)."""
         c = ctx or self.ctx
+        self._check_len(witness)
         out = ctypes.create_string_buffer(256)
         flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
         c._check(c._lib.g16_prove(c._h, self._h, _buf(witness), flags, _buf(r) if r else None,
@@ -309,6 +316,7 @@ class ProvingKey:
     def prove_partials(self, witness, mont: bool = True, device: bool = False, out=None, ctx=None):
         """this rank's five XYZZ MSM partials (768 bytes); out = device pointer to write them into HBM."""
         c = ctx or self.ctx
+        self._check_len(witness)
         flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
         if out is not None:
             c._check(c._lib.g16_prove_partials(c._h, self._h, _buf(witness), flags | OUT_DEVICE, _buf(out)))
@@ -327,6 +335,7 @@ class ProvingKey:
 
     def build_abc(self, witness: bytes, mont: bool = True, ctx=None):
         c = ctx or self.ctx
+        self._check_len(witness)
         n = 1 << self.log2n
         out = ctypes.create_string_buffer(3 * n * 32)
         c._check(c._lib.g16_build_abc(c._h, self._h, _buf(witness), SCALARS_MONT if mont else 0, out))

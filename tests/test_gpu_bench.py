@@ -1,0 +1,55 @@
+"""bench.py end to end on the GPU box at a small domain: the plain single-GPU command, and the plain
+`--gpus 2 --mode shard --backend gloo` command from a bare shell (two self-launched ranks sharing the box's one GPU,
+the real g16_prove_partials / g16_prove_combine on both, the exchange over gloo).  Both must pass bench.py's own gate
+(every distinct witness's proof bit-exact against the CPU oracle) and print ONE contract line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _run(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert "correctness gate passed for 3 distinct witnesses" in r.stderr
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1000)
+def test_bench_single_gpu_small_domain_contract_line():
+    d = _run("--log2n", "14", "--steps", "12", "--warmup", "3")
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+    assert "witness from host" in d["config"]["inputs"] and d["value_witness_in_hbm"] > 0
+    assert d["keys_resident_per_gpu"] == 1 and d["proofs_in_flight_per_gpu"] == 3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+
+
+@pytest.mark.timeout(1000)
+def test_bench_two_ranks_shard_mode_from_a_bare_shell():
+    d = _run("--gpus", "2", "--mode", "shard", "--backend", "gloo", "--log2n", "14", "--steps", "6", "--warmup", "3")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "shard" and d["value"] > 0
+    assert d["cpu_baseline"] is None                       # reported at N = 1 only
+
+
+@pytest.mark.timeout(1000)
+def test_bench_two_ranks_replica_mode_from_a_bare_shell():
+    d = _run("--gpus", "2", "--backend", "gloo", "--log2n", "13", "--steps", "6", "--warmup", "3", "--inflight", "2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["mode"] == "replica"
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]     # whole-job aggregate over both ranks
