@@ -2,8 +2,8 @@
 // (groth16/math/ntt.nim:17-161): natural order in and out, forward unscaled
 // y_k = sum_i x_i w^(ik), inverse scaled by 1/n, w = gen28^(2^(28-log2 n)) (math/domain.nim:26-33).
 //
-// The reference recursion is replaced by a Stockham auto-sort decomposition in <= 4 passes; every pass
-// performs up to 8 radix-2 DIF butterfly stages of a size-R sub-transform inside LDS:
+// The reference recursion is replaced by a Stockham auto-sort decomposition in <= 3 passes (2 up to n = 2^20); every
+// pass performs up to 10 radix-2 DIF butterfly stages of a size-R sub-transform inside LDS:
 //   pass with stride s (product of earlier radices), l = n / (s R):
 //     for base = k + s*j  (k < s, j < l):   Z_q = sum_r x[base + (n/R) r] w_R^(r q)      (LDS butterflies)
 //                                           y[k + s (R j + q)] = Z_q * w_n^(s j q)        (inter-pass twiddle)
@@ -59,45 +59,32 @@ __device__ __forceinline__ u256 ntt_tw(const u256* __restrict__ tw, uint32_t e, 
   return Fr::neg(tw[e - half]);
 }
 
-constexpr int NTT_BLOCK = 256;
-constexpr int NTT_TILE = 2048;  // elements per workgroup tile (64 KB of LDS)
+// Workgroup geometry.  A workgroup of NTT_BLOCK threads owns a tile of up to NTT_TILE elements = B bases x R points
+// (R = 2^rho <= 1024): 128 KB of the CU's 160 KB LDS + 16 KB of inner twiddles, one workgroup per CU, 4 waves per
+// SIMD.  With rho up to 10 a 2^20 transform is TWO passes (10 + 10 stages; 2^21..2^30: three), and a tile still
+// covers B >= 4 consecutive bases, i.e. whole 128-byte lines on every global access.
+constexpr int NTT_BLOCK = 1024;
+constexpr int NTT_TILE = 4096;
+constexpr uint32_t NTT_MAX_RHO = 10;
 
-__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return __brev(x) >> (32 - bits); }
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? __brev(x) >> (32 - bits) : 0u; }
 
-// one pass: rho radix-2 stages of B sub-transforms of size R = 2^rho per workgroup.
-// blockIdx.y selects one of several independent vectors (x + y*xstride -> y + y*ystride): the prover
-// transforms Az, Bz, Cz together (prover.nim:167-169 runs them as three tasks).
-// `scale` (last pass only): out[i] *= scale[i] instead of the plain 1/n of the inverse transform -- used
-// to fuse multiplyByPowers (prover.nim:96-106) into the inverse NTT of shiftEvalDomain (prover.nim:109-113).
-static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restrict__ x, u256* __restrict__ y,
-                                                      const u256* __restrict__ tw, uint32_t log2n, uint32_t log2s,
-                                                      uint32_t rho, uint32_t log2b, int inverse, int last,
-                                                      size_t xstride, size_t ystride,
-                                                      const u256* __restrict__ scale) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  u256* lds = reinterpret_cast<u256*>(smem);
-  x += xstride * blockIdx.y;
-  y += ystride * blockIdx.y;
-  const uint32_t R = 1u << rho, B = 1u << log2b;
-  const uint32_t nR = 1u << (log2n - rho);  // n / R = number of bases = input stride between r's
-  const uint32_t base0 = blockIdx.x << log2b;
-  const uint32_t tile = R << log2b;
-  const uint32_t tid = threadIdx.x;
+// Tile order: consecutive tiles touch neighbouring 128-byte lines of every strided row, and workgroups are dealt
+// round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Giving XCD x the contiguous tile range
+// [x*T/8, (x+1)*T/8) keeps those neighbours in ONE L2 instead of fetching the line into two.  Speed only: any
+// bijection is correct.
+__device__ __forceinline__ uint32_t ntt_tile_of_block(uint32_t bid, uint32_t ntiles) {
+  return (ntiles & 7u) ? bid : (bid & 7u) * (ntiles >> 3) + (bid >> 3);
+}
 
-  // inner-stage twiddles w_R^t (t < R/2) once per workgroup into LDS, behind the tile
-  u256* twl = lds + tile;
-  for (uint32_t t = tid; t < (R >> 1); t += NTT_BLOCK) twl[t] = ntt_tw(tw, t << (log2n - rho), log2n, inverse);
-  // load: element (r, b) <- x[base0 + b + nR * r]   (LDS index r*B + b)
-  for (uint32_t e = tid; e < tile; e += NTT_BLOCK) {
-    uint32_t b = e & (B - 1), r = e >> log2b;
-    lds[e] = x[(size_t)base0 + b + (size_t)nR * r];
-  }
-  __syncthreads();
-
-  // rho DIF stages: half distance h = R/2 ... 1 ; twiddle w_(2h)^p = w_R^(p * R/(2h))
+// rho DIF stages on the tile in LDS (rows r = 0..R-1 of B elements; output row bitrev(q) holds Z_q)
+template <int BLOCK>
+__device__ __forceinline__ void ntt_tile_stages(u256* lds, const u256* twl, uint32_t rho, uint32_t log2b,
+                                                uint32_t tile) {
+  const uint32_t tid = threadIdx.x, B = 1u << log2b;
   for (uint32_t lh = rho; lh-- > 0;) {
     const uint32_t h = 1u << lh;
-    for (uint32_t bf = tid; bf < (tile >> 1); bf += NTT_BLOCK) {
+    for (uint32_t bf = tid; bf < (tile >> 1); bf += BLOCK) {
       uint32_t b = bf & (B - 1), pi = bf >> log2b;
       uint32_t p = pi & (h - 1);
       uint32_t i = ((pi >> lh) << (lh + 1)) | p;
@@ -110,10 +97,45 @@ static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restr
     }
     __syncthreads();
   }
+}
+
+// one pass: rho radix-2 stages of B sub-transforms of size R = 2^rho per workgroup.
+// blockIdx.y selects one of several independent vectors (x + y*xstride -> y + y*ystride): the prover
+// transforms Az, Bz, Cz together (prover.nim:167-169 runs them as three tasks).
+// `scale` (last pass only): out[i] *= scale[i] instead of the plain 1/n of the inverse transform -- used
+// to fuse multiplyByPowers (prover.nim:96-106) into the inverse NTT of shiftEvalDomain (prover.nim:109-113).
+template <int BLOCK>
+static __global__ void __launch_bounds__(BLOCK) ntt_pass(const u256* __restrict__ x, u256* __restrict__ y,
+                                                      const u256* __restrict__ tw, uint32_t log2n, uint32_t log2s,
+                                                      uint32_t rho, uint32_t log2b, int inverse, int last,
+                                                      size_t xstride, size_t ystride,
+                                                      const u256* __restrict__ scale) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u256* lds = reinterpret_cast<u256*>(smem);
+  x += xstride * blockIdx.y;
+  y += ystride * blockIdx.y;
+  const uint32_t R = 1u << rho, B = 1u << log2b;
+  const uint32_t nR = 1u << (log2n - rho);  // n / R = number of bases = input stride between r's
+  const uint32_t base0 = ntt_tile_of_block(blockIdx.x, gridDim.x) << log2b;
+  const uint32_t tile = R << log2b;
+  const uint32_t tid = threadIdx.x;
+
+  // inner-stage twiddles w_R^t (t < R/2) once per workgroup into LDS, behind the tile
+  u256* twl = lds + tile;
+  for (uint32_t t = tid; t < (R >> 1); t += BLOCK) twl[t] = ntt_tw(tw, t << (log2n - rho), log2n, inverse);
+  // load: element (r, b) <- x[base0 + b + nR * r]   (LDS index r*B + b)
+  for (uint32_t e = tid; e < tile; e += BLOCK) {
+    uint32_t b = e & (B - 1), r = e >> log2b;
+    lds[e] = x[(size_t)base0 + b + (size_t)nR * r];
+  }
+  __syncthreads();
+
+  // rho DIF stages: half distance h = R/2 ... 1 ; twiddle w_(2h)^p = w_R^(p * R/(2h))
+  ntt_tile_stages<BLOCK>(lds, twl, rho, log2b, tile);
 
   // store: Z_q (at LDS row bitrev(q)) * w^(s j q)  ->  y[k + s (R j + q)]
   const uint32_t s_mask = (1u << log2s) - 1;
-  for (uint32_t e = tid; e < tile; e += NTT_BLOCK) {
+  for (uint32_t e = tid; e < tile; e += BLOCK) {
     uint32_t b = e & (B - 1), q = e >> log2b;
     uint32_t base = base0 + b;
     uint32_t k = base & s_mask, j = base >> log2s;
@@ -133,6 +155,63 @@ static __global__ void __launch_bounds__(NTT_BLOCK) ntt_pass(const u256* __restr
   }
 }
 
+// LAST forward pass of the quotient with the pointwise step fused in: the workgroup runs the same tile of the three
+// vectors A, B, C (x, x + xstride, x + 2 xstride) one after the other through LDS and keeps, per output element,
+//   acc = A1 ;  acc *= B1 ;  acc -= C1          ( ys[j] = A1[j]*B1[j] - C1[j], prover.nim:175-176 )
+// in registers ( * invZ1 = -1/2 for the JensGroth flavour, prover.nim:127-128,141 ), so the three transformed
+// vectors are never written to HBM: out receives n elements instead of 3n written + 3n read + n written.
+template <int BLOCK>
+static __global__ void __launch_bounds__(BLOCK) ntt_last_pass_abc(const u256* __restrict__ x, u256* __restrict__ out,
+                                                               const u256* __restrict__ tw, uint32_t log2n,
+                                                               uint32_t log2s, uint32_t rho, uint32_t log2b,
+                                                               size_t xstride, int mul_invz) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u256* lds = reinterpret_cast<u256*>(smem);
+  constexpr int PER = NTT_TILE / BLOCK;   // output elements per thread (the tile may be smaller: guarded)
+  const uint32_t R = 1u << rho, B = 1u << log2b;
+  const uint32_t nR = 1u << (log2n - rho);
+  const uint32_t base0 = ntt_tile_of_block(blockIdx.x, gridDim.x) << log2b;
+  const uint32_t tile = R << log2b;
+  const uint32_t tid = threadIdx.x;
+  u256* twl = lds + tile;
+  for (uint32_t t = tid; t < (R >> 1); t += BLOCK) twl[t] = ntt_tw(tw, t << (log2n - rho), log2n, 0);
+  u256 acc[PER];
+#pragma unroll 1
+  for (int v = 0; v < 3; ++v) {
+    const u256* xv = x + xstride * v;
+    for (uint32_t e = tid; e < tile; e += BLOCK) {
+      uint32_t b = e & (B - 1), r = e >> log2b;
+      lds[e] = xv[(size_t)base0 + b + (size_t)nR * r];
+    }
+    __syncthreads();
+    ntt_tile_stages<BLOCK>(lds, twl, rho, log2b, tile);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const uint32_t e = tid + i * BLOCK;
+      if (e < tile) {
+        uint32_t b = e & (B - 1), q = e >> log2b;
+        u256 z = lds[(bitrev(q, rho) << log2b) | b];
+        acc[i] = v == 0 ? z : v == 1 ? Fr::mul(acc[i], z) : Fr::sub(acc[i], z);
+      }
+    }
+    __syncthreads();   // the tile is overwritten by the next vector
+  }
+  const uint32_t s_mask = (1u << log2s) - 1;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const uint32_t e = tid + i * BLOCK;
+    if (e < tile) {
+      uint32_t b = e & (B - 1), q = e >> log2b;
+      uint32_t base = base0 + b;
+      uint32_t k = base & s_mask, j = base >> log2s;
+      const size_t oi = (size_t)k + ((size_t)(((size_t)j << rho) + q) << log2s);
+      u256 r = acc[i];
+      if (mul_invz) r = Fr::neg(Fr::div2(r));   // invZ1 = 1/(eta^n - 1) = -1/2
+      out[oi] = r;
+    }
+  }
+}
+
 // scale tables for the coset shift, eta = w_(2n) (prover.nim:163):
 //   mode 0: tab[i] = eta^i / n      (inverse NTT + multiplyByPowers(eta),    prover.nim:110-112)
 //   mode 1: tab[i] = eta^(-i) / n   (inverse NTT + multiplyByPowers(1/eta),  prover.nim:142-143)
@@ -145,20 +224,6 @@ static __global__ void __launch_bounds__(256) ntt_make_coset_table(u256* __restr
   u256 eta = ntt_omega(log2n + 1);
   uint32_t e = mode ? (2 * n - i) % (2 * n) : i;   // eta^(2n) = 1
   tab[i] = Fr::mul(fr_pow_u32(eta, e), ninv);
-}
-
-// ys[j] = (A1[j]*B1[j] - C1[j]) [* invZ]   (prover.nim:175-176 and :141)
-static __global__ void __launch_bounds__(256) fr_abc_pointwise(const u256* __restrict__ a, const u256* __restrict__ b,
-                                                        const u256* __restrict__ c, u256* __restrict__ out,
-                                                        uint32_t n, int mul_invz, uint32_t log2n) {
-  uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  u256 v = Fr::sub(Fr::mul(a[j], b[j]), c[j]);
-  if (mul_invz) {
-    // invZ1 = 1 / (eta^n - 1), eta = w_(2n)  =>  eta^n = -1  =>  invZ1 = -1/2   (prover.nim:127-128)
-    v = Fr::neg(Fr::div2(v));
-  }
-  out[j] = v;
 }
 
 }  // namespace g16

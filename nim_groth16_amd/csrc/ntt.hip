@@ -16,36 +16,65 @@ static int32_t ensure_twiddles(g16_ctx* ctx, uint32_t log2n) {
   return G16_OK;
 }
 
+// dynamic LDS of a pass: tile + R/2 inner twiddles.  Up to 144 KB: above the 64 KB default, so the kernels are
+// opted in once per process.
+static size_t pass_shmem(uint32_t rho, uint32_t log2b) { return (size_t(32) << (rho + log2b)) + (size_t(16) << rho); }
+static int32_t ntt_kernels_init(g16_ctx* ctx) {
+  static bool done = false;   // benign race: the attribute is idempotent
+  if (done) return G16_OK;
+  const int max_shmem = (int)pass_shmem(NTT_MAX_RHO, 2);
+  static_assert((size_t(32) * NTT_TILE) + (size_t(16) << NTT_MAX_RHO) <= 160 * 1024, "tile + twiddles must fit the LDS");
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass<NTT_BLOCK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_last_pass_abc<NTT_BLOCK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
+  done = true;
+  return G16_OK;
+}
+
 // `batch` independent transforms: in + b*in_stride -> out + b*out_stride (strides in elements).
-// in may equal out.  scale: optional per-output-index factor applied in the last pass (replaces 1/n).
+// `in` may equal `out` only for multi-pass sizes (log2n > NTT_MAX_RHO), where the first pass writes to a temporary.
+// scale: optional per-output-index factor applied in the last pass (replaces 1/n).
+// fuse_abc (forward, batch == 3 only): the last pass multiplies / subtracts the three transformed vectors on the fly
+// and writes ONE vector to `out` (ntt_last_pass_abc); fuse_abc == 2 additionally multiplies by invZ1.
 static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256* out, size_t out_stride,
-                           uint32_t batch, uint32_t log2n, int inverse, const u256* scale) {
+                           uint32_t batch, uint32_t log2n, int inverse, const u256* scale, int fuse_abc = 0) {
   const size_t n = size_t(1) << log2n;
   int32_t rc;
   if ((rc = ensure_twiddles(ctx, log2n))) return rc;
-  if (log2n == 0) {
+  if ((rc = ntt_kernels_init(ctx))) return rc;
+  if (log2n == 0 && !fuse_abc) {
     for (uint32_t b = 0; b < batch; ++b)
       HIPCHK(ctx, hipMemcpyAsync(out + b * out_stride, in + b * in_stride, 32, hipMemcpyDeviceToDevice, ctx->stream));
     return G16_OK;  // n = 1: 1/n = 1 and eta^0 = 1
   }
-  const uint32_t npass = (log2n + 7) / 8;
-  if ((rc = ensure(ctx, ctx->ntt_tmp, 2 * n * 32 * batch))) return rc;
-  u256* tmpA = (u256*)ctx->ntt_tmp.p;
-  u256* tmpB = tmpA + n * batch;
+  // passes of <= 10 stages: one up to 2^10, two up to 2^20, three beyond
+  const uint32_t npass = log2n ? (log2n + NTT_MAX_RHO - 1) / NTT_MAX_RHO : 1;
+  u256 *tmpA = nullptr, *tmpB = nullptr;
+  if (npass > 1) {
+    if ((rc = ensure(ctx, ctx->ntt_tmp, (npass > 2 ? 2 : 1) * n * 32 * batch))) return rc;
+    tmpA = (u256*)ctx->ntt_tmp.p;
+    tmpB = tmpA + n * batch;
+  }
   const u256* src = in;
   size_t src_stride = in_stride;
   uint32_t log2s = 0;
   for (uint32_t p = 0; p < npass; ++p) {
     uint32_t rho = log2n / npass + (p < log2n % npass ? 1u : 0u);
-    uint32_t log2b = 10 - rho;   // 1024-element (32 KB) tiles: 4 workgroups per CU
+    uint32_t log2b = 12 - rho;   // NTT_TILE = 2^12 elements
     if (log2b > log2n - rho) log2b = log2n - rho;
     const bool last = p + 1 == npass;
+    const size_t shmem = pass_shmem(rho, log2b);
+    const uint32_t ntiles = 1u << (log2n - rho - log2b);
+    if (last && fuse_abc) {
+      KLAUNCH(ctx, "ntt_last_pass_abc", ntt_last_pass_abc<NTT_BLOCK>, ntiles, NTT_BLOCK, shmem, src, out,
+              (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, src_stride, fuse_abc == 2 ? 1 : 0);
+      break;
+    }
     u256* dst = last ? out : ((p & 1) ? tmpB : tmpA);
     const size_t dst_stride = last ? out_stride : n;
-    const dim3 grid(1u << (log2n - rho - log2b), batch);
-    const size_t shmem = (size_t(32) << (rho + log2b)) + (size_t(16) << rho);   // tile + R/2 twiddles
-    KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass, grid, NTT_BLOCK, shmem, src, dst,
-            (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse, last ? 1 : 0, src_stride, dst_stride,
+    KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK>, dim3(ntiles, batch), NTT_BLOCK, shmem,
+            src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse, last ? 1 : 0, src_stride, dst_stride,
             last ? scale : (const u256*)nullptr);
     src = dst;
     src_stride = dst_stride;
@@ -56,6 +85,13 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
 }
 
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse) {
+  if (d_src == d_dst && log2n <= NTT_MAX_RHO && log2n > 0) {   // single pass: never in place
+    int32_t rc = ensure(ctx, ctx->ntt_tmp, (size_t(32) << log2n));
+    if (rc) return rc;
+    if ((rc = ntt_batched(ctx, (const u256*)d_src, 0, (u256*)ctx->ntt_tmp.p, 0, 1, log2n, inverse, nullptr))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, ctx->ntt_tmp.p, size_t(32) << log2n, hipMemcpyDeviceToDevice, ctx->stream));
+    return G16_OK;
+  }
   return ntt_batched(ctx, (const u256*)d_src, 0, (u256*)d_dst, 0, 1, log2n, inverse, nullptr);
 }
 
@@ -70,6 +106,11 @@ static int32_t ensure_coset(g16_ctx* ctx, uint32_t log2n, int mode) {
   return G16_OK;
 }
 
+// Quotient pipeline.  Snarkjs flavour at n = 2^20: FOUR launches, each reading or writing every vector once --
+//   inverse pass 1 (A|B|C batched)  ->  inverse pass 2 with eta^i/n fused  ->  forward pass 1  ->  forward pass 2
+//   with A1*B1 - C1 fused (one vector out).
+// Az | Bz | Cz are read where they lie when they are contiguous (they are, in the per-proof buffer of
+// g16_prove_partials): no staging copies.  HBM bytes: (6 + 6 + 6 + 4) * 32 n = 704 n.
 int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, uint32_t log2n,
                             int flavour, void* d_out) {
   if (log2n > 27) {
@@ -78,23 +119,30 @@ int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, cons
   }
   const size_t n = size_t(1) << log2n;
   int32_t rc;
-  if ((rc = ensure(ctx, ctx->quot, 6 * n * 32))) return rc;
+  if ((rc = ensure(ctx, ctx->quot, 4 * n * 32))) return rc;
   if ((rc = ensure_coset(ctx, log2n, 0))) return rc;
-  u256* X = (u256*)ctx->quot.p;
+  u256* X = (u256*)ctx->quot.p;   // 3n: coset coefficients  |  n: JensGroth intermediate
   u256* Y = X + 3 * n;
-  HIPCHK(ctx, hipMemcpyAsync(X, d_a, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(X + n, d_b, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(X + 2 * n, d_c, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-  // shiftEvalDomain x3 (prover.nim:109-113, 167-169): iNTT with eta^i/n folded in, then forward NTT
-  if ((rc = ntt_batched(ctx, X, n, Y, n, 3, log2n, 1, (const u256*)ctx->coset[0].p))) return rc;
-  if ((rc = ntt_batched(ctx, Y, n, X, n, 3, log2n, 0, nullptr))) return rc;
-  const uint32_t grid = (uint32_t)((n + 255) / 256);
-  if (flavour == 1) {  // Snarkjs: ys = A1*B1 - C1   (prover.nim:175-176)
-    KLAUNCH(ctx, "fr_abc_pointwise", fr_abc_pointwise, grid, 256, 0, X, X + n, X + 2 * n, (u256*)d_out, (uint32_t)n, 0,
-            log2n);
-  } else {  // JensGroth: (A1*B1 - C1) * invZ1, iNTT, * eta^-i   (prover.nim:141-143)
+  const u256* in = (const u256*)d_a;
+  if ((const u256*)d_b != in + n || (const u256*)d_c != in + 2 * n) {   // scattered inputs (generic C-ABI callers)
+    HIPCHK(ctx, hipMemcpyAsync(X, d_a, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(X + n, d_b, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(X + 2 * n, d_c, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    in = X;
+    if (log2n <= NTT_MAX_RHO) {   // a single pass cannot run in place: stage behind the work area
+      if ((rc = ensure(ctx, ctx->ntt_tmp, 3 * n * 32))) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->ntt_tmp.p, X, 3 * n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+      in = (const u256*)ctx->ntt_tmp.p;
+    }
+  }
+  // shiftEvalDomain x3 (prover.nim:109-113, 167-169): iNTT with eta^i/n folded in, then forward NTT whose last pass
+  // forms A1*B1 - C1 (prover.nim:175-176) [* invZ1, prover.nim:141]
+  if ((rc = ntt_batched(ctx, in, n, X, n, 3, log2n, 1, (const u256*)ctx->coset[0].p))) return rc;
+  if (flavour == 1) {  // Snarkjs
+    if ((rc = ntt_batched(ctx, X, n, (u256*)d_out, 0, 3, log2n, 0, nullptr, 1))) return rc;
+  } else {  // JensGroth: ... * invZ1, iNTT, * eta^-i   (prover.nim:141-143)
     if ((rc = ensure_coset(ctx, log2n, 1))) return rc;
-    KLAUNCH(ctx, "fr_abc_pointwise", fr_abc_pointwise, grid, 256, 0, X, X + n, X + 2 * n, Y, (uint32_t)n, 1, log2n);
+    if ((rc = ntt_batched(ctx, X, n, Y, 0, 3, log2n, 0, nullptr, 2))) return rc;
     if ((rc = ntt_batched(ctx, Y, n, (u256*)d_out, n, 1, log2n, 1, (const u256*)ctx->coset[1].p))) return rc;
   }
   HIPCHK(ctx, hipGetLastError());

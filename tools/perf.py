@@ -28,11 +28,14 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dist", choices=["uniform", "circom"], default="uniform",
                     help="circom: 40 %% zero, 30 %% one, 10 %% < 2^16, 20 %% uniform (SURVEY 8d config 2-ii)")
+    ap.add_argument("--only", choices=["all", "ntt"], default="all", help="ntt: NTT + quotient timings only")
     args = ap.parse_args()
     n = 1 << args.log2n
     orc = load_oracle()
     ctx = Context(0)
     ctx.selftest()
+    if args.only == "ntt":
+        return ntt_part(ctx, args, torch.frombuffer(bytearray(rand_fr_mont_bytes(4 * n, 2)), dtype=torch.uint8).cuda())
     t = time.time()
     kb = rand_fr_mont_bytes(n, 1)
     p1 = orc.fixed_base(1, kb)
@@ -100,18 +103,36 @@ def main():
         for _ in range(args.reps):
             fn()
         print(f"   wall without profiling: {(time.time()-t)/args.reps*1e3:.3f} ms/call")
-    # NTT
-    d_x = d_s
-    d_y = torch.empty_like(d_x)
-    fn = lambda: ctx.ntt(d_x.data_ptr(), args.log2n, False, dst=d_y.data_ptr(), device=True)
-    fn(); ctx.synchronize()
-    ctx.profile(True); ctx.profile_reset()
-    for _ in range(args.reps):
-        fn()
-    rep = ctx.profile_report(); ctx.profile(False)
-    print(f"== ntt fwd n=2^{args.log2n}")
-    for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"]):
-        print(f"   {k:20s} {v['total_ms']/args.reps:9.3f} ms  ({v['calls']//args.reps} launches)")
+    ntt_part(ctx, args, torch.frombuffer(bytearray(rand_fr_mont_bytes(4 * n, 2)), dtype=torch.uint8).cuda())
+
+
+def ntt_part(ctx, args, d_buf):
+    """d_buf: 4n Fr elements in HBM (Az | Bz | Cz | out)"""
+    n = 1 << args.log2n
+    base = d_buf.data_ptr()
+    d_y = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    cases = [("ntt fwd", lambda: ctx.ntt(base, args.log2n, False, dst=d_y.data_ptr(), device=True)),
+             ("ntt inv", lambda: ctx.ntt(base, args.log2n, True, dst=d_y.data_ptr(), device=True)),
+             ("quotient snarkjs (6 NTT + pointwise)",
+              lambda: ctx.quotient(base, base + 32 * n, base + 64 * n, args.log2n, 1, out=base + 96 * n, device=True)),
+             ("quotient jensgroth (7 NTT + pointwise)",
+              lambda: ctx.quotient(base, base + 32 * n, base + 64 * n, args.log2n, 0, out=base + 96 * n, device=True))]
+    for name, fn in cases:
+        fn(); ctx.synchronize()
+        ctx.profile(True); ctx.profile_reset()
+        for _ in range(args.reps):
+            fn()
+        rep = ctx.profile_report(); ctx.profile(False)
+        tot = sum(v["total_ms"] for v in rep.values()) / args.reps
+        print(f"== {name} n=2^{args.log2n}: {tot:.3f} ms in kernels")
+        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"]):
+            print(f"   {k:20s} {v['total_ms']/args.reps:9.3f} ms  ({v['calls']//args.reps} launches)")
+        ctx.synchronize()
+        t = time.time()
+        for _ in range(10):
+            fn()
+        ctx.synchronize()
+        print(f"   wall without profiling: {(time.time()-t)/10*1e3:.3f} ms/call")
 
 
 if __name__ == "__main__":
