@@ -615,45 +615,115 @@ __global__ void __launch_bounds__(BLOCK) msm_reduce2(const typename C::Acc* __re
   if (threadIdx.x == 0) window_sum[w] = tot;
 }
 
+// ---- wave-cooperative doubling for the serial tails -----------------------------------------------------
+// A doubling chain on ONE lane is bound by the issue rate of its wave (~2800 instructions, ~7 us per doubling on
+// MI355X) while 63 lanes idle.  The 9 multiplications + 1 two-term product of dbl-2008-s-1 fall into three levels
+// of mutually independent products:
+//   level 1:  v = u^2          xx = x^2                        (u = 2y)
+//   level 2:  w = u v          s  = x v          mm = m^2      (m = 3 xx)
+//   level 3:  y3 = m (s - x3) - w y      zz3 = v zz      zzz3 = w zzz        (x3 = mm - 2s)
+// Lanes 0, 1, 2 of the wave take one product of a level each -- the SAME instruction stream on different operands,
+// so nothing diverges -- and the results travel between levels by ds_bpermute.  One doubling then costs 3 (+1/2)
+// multiplications of wave time instead of 10 1/2.  Every lane holds the same point on entry and on exit; the
+// formulas map the all-zero infinity to itself, so no lane branches.
+__device__ __forceinline__ u256 wave_get(const u256& v, int src) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = __shfl(v.v[i], src, 64);
+  return r;
+}
+__device__ __forceinline__ fp2_t wave_get(const fp2_t& v, int src) { return fp2_t{wave_get(v.c0, src), wave_get(v.c1, src)}; }
+template <class E>
+__device__ __forceinline__ E sel3(uint32_t role, const E& a, const E& b, const E& c) {
+  return role == 0 ? a : (role == 1 ? b : c);
+}
+template <class C>
+__device__ __forceinline__ typename C::Acc dbl_coop(const typename C::Acc& p) {
+  using F = typename C::Field;
+  using E = typename C::E;
+  const uint32_t lane = threadIdx.x & 63, role = lane < 2 ? lane : 2;
+  const E u = F::dbl(p.y);
+  const E l1 = F::sqr(role == 0 ? u : p.x);
+  const E v = wave_get(l1, 0), xx = wave_get(l1, 1);
+  const E m = F::add(F::dbl(xx), xx);
+  const E l2 = F::mul(sel3(role, u, p.x, m), role == 2 ? m : v);
+  const E w = wave_get(l2, 0), s = wave_get(l2, 1), mm = wave_get(l2, 2);
+  const E x3 = F::sub(mm, F::dbl(s));
+  // a b - c d on every lane (c = 0 on lanes 1, 2: the plain product through the same code path)
+  const E l3 = F::mulsub(sel3(role, m, v, w), sel3(role, F::sub(s, x3), p.zz, p.zzz), role == 0 ? w : F::zero(), p.y);
+  return typename C::Acc{x3, wave_get(l3, 0), wave_get(l3, 1), wave_get(l3, 2)};
+}
+
 // ---- K7: fold windows + canonical affine ------------------------------------------------------------
 // c > 0: Horner  sum_w 2^(c w) S_w  (c doublings per window: a serial chain of ~254 doublings);
 // c == 0: the window sums already carry their 2^(c w) factor (precomputed tables) -> plain sum.
+// One wave; every lane carries the same running point, the doublings are wave-cooperative (dbl_coop).
 template <class C>
-__global__ void msm_fold(const typename C::Acc* __restrict__ window_sum, uint32_t nwin, uint32_t c,
-                         typename C::Aff* __restrict__ out_aff, typename C::Acc* __restrict__ out_acc) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(64) msm_fold(const typename C::Acc* __restrict__ window_sum, uint32_t nwin, uint32_t c,
+                                               typename C::Aff* __restrict__ out_aff,
+                                               typename C::Acc* __restrict__ out_acc) {
   typename C::Acc r = C::acc_inf();
   for (int w = (int)nwin - 1; w >= 0; --w) {
-    if (!C::is_inf(r))
-      for (uint32_t i = 0; i < c; ++i) r = C::dbl(r);
+    if (!C::is_inf(r))   // uniform: r is the same on every lane
+#pragma unroll 1
+      for (uint32_t i = 0; i < c; ++i) r = dbl_coop<C>(r);
     C::add(r, window_sum[w]);
   }
-  if (out_acc) *out_acc = r;
-  if (out_aff) *out_aff = C::to_affine(r);
+  if (threadIdx.x == 0) {
+    if (out_acc) *out_acc = r;
+    if (out_aff) *out_aff = C::to_affine(r);
+  }
 }
 
 // ---- K7': fold for the merged bucket set of a registered point set ------------------------------------
-// The 2^(c-1) buckets were reduced in `nsets` slices of Ks = 2^log2ks buckets with slice-local weights
+// The 2^(c-1) buckets were reduced in `nsets` <= 64 slices of Ks = 2^log2ks buckets with slice-local weights
 // 1..Ks; slice v starts at bucket v*Ks, so   S = sum_v S_v + Ks * sum_v v * Tot_v .
-// One wave: lane v forms v*Tot_v, LDS trees add the lanes, lane 0 applies the log2(Ks) doublings.
+// Two waves, no LDS trees: wave 1 all-reduces the S_v; wave 0 forms sum_v v Tot_v as the sum over v >= 1 of the
+// suffix sums of Tot (one shuffle scan + one shuffle all-reduce: 12 additions, no per-lane double-and-add), applies
+// the log2(Ks) doublings cooperatively (dbl_coop) and finishes.
 template <class C>
-__global__ void __launch_bounds__(64) msm_fold_merged(const typename C::Acc* __restrict__ set_sum,
-                                                      const typename C::Acc* __restrict__ set_tot, uint32_t nsets,
-                                                      uint32_t log2ks, typename C::Aff* __restrict__ out_aff,
-                                                      typename C::Acc* __restrict__ out_acc) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
-  const uint32_t v = threadIdx.x;
-  typename C::Acc x = C::acc_inf(), y = C::acc_inf();
-  if (v < nsets) {
-    y = set_sum[v];
-    if (v) x = C::mul_small(set_tot[v], v);
+__device__ __forceinline__ typename C::Acc wave_get_acc(const typename C::Acc& a, int src) {
+  return typename C::Acc{wave_get(a.x, src), wave_get(a.y, src), wave_get(a.zz, src), wave_get(a.zzz, src)};
+}
+template <class C>
+__device__ __forceinline__ typename C::Acc wave_allreduce(typename C::Acc v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int d = 1; d < 64; d <<= 1) {
+    typename C::Acc other = wave_get_acc<C>(v, lane ^ d);
+    C::add(v, other);
   }
-  typename C::Acc xs = block_sum<C, 64>(x, sh);
-  typename C::Acc ys = block_sum<C, 64>(y, sh);
-  if (v == 0) {
-    for (uint32_t i = 0; i < log2ks; ++i) xs = C::dbl(xs);
-    C::add(xs, ys);
+  return v;   // the same total on every lane (group addition is commutative; the result is made canonical later)
+}
+template <class C>
+__global__ void __launch_bounds__(128) msm_fold_merged(const typename C::Acc* __restrict__ set_sum,
+                                                       const typename C::Acc* __restrict__ set_tot, uint32_t nsets,
+                                                       uint32_t log2ks, typename C::Aff* __restrict__ out_aff,
+                                                       typename C::Acc* __restrict__ out_acc) {
+  __shared__ typename C::Acc ysum;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 1) {
+    typename C::Acc y = (uint32_t)lane < nsets ? set_sum[lane] : C::acc_inf();
+    y = wave_allreduce<C>(y);
+    if (lane == 0) ysum = y;
+  }
+  typename C::Acc xs = C::acc_inf();
+  if (wave == 0) {
+    // inclusive suffix scan of Tot over the lanes, then sum the suffixes of v = 1 .. nsets-1
+    typename C::Acc suf = (uint32_t)lane < nsets ? set_tot[lane] : C::acc_inf();
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+      typename C::Acc other = wave_get_acc<C>(suf, (lane + d) & 63);
+      if (lane + d < 64) C::add(suf, other);
+    }
+    if (lane == 0) suf = C::acc_inf();   // v = 0 carries weight 0
+    xs = wave_allreduce<C>(suf);
+#pragma unroll 1
+    for (uint32_t i = 0; i < log2ks; ++i) xs = dbl_coop<C>(xs);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    C::add(xs, ysum);
     if (out_acc) *out_acc = xs;
     if (out_aff) *out_aff = C::to_affine(xs);
   }

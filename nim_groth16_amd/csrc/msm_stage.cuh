@@ -53,10 +53,15 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::M
   const bool g2 = sizeof(typename C::Aff) == 128;
   const size_t nchunks = P.nbuckets / RED_CHUNK;
   auto* wsum = (typename C::Acc*)wsum_;
-  // reduction sets: the windows themselves, or <= 64 slices of 2048 chunks of the merged bucket set
+  // reduction sets: the windows themselves, or <= 64 slices of the merged bucket set.  reduce2 is a latency chain
+  // whose length grows with the chunks per thread, so the slices are as small as the 64 lanes of msm_fold_merged
+  // allow: 512 chunks (2^13 buckets) per slice at c = 20 -> 64 workgroups, one chunk per thread (G1) / two (G2).
+  // G16_RED_SLICE = log2(chunks per slice) overrides it (experiments).
   uint32_t nsets = P.nwin, log2ks = 0;
   if (P.tables) {
-    uint32_t cps = nchunks < 2048 ? (uint32_t)nchunks : 2048u;
+    const uint32_t want = 1u << (g16_env().red_slice_log2 ? g16_env().red_slice_log2 : 9);
+    uint32_t cps = nchunks < want ? (uint32_t)nchunks : want;
+    while (nchunks / cps > 64) cps <<= 1;
     nsets = (uint32_t)(nchunks / cps);
     for (uint32_t ks = cps * RED_CHUNK; ks > 1; ks >>= 1) ++log2ks;
   }
@@ -66,8 +71,8 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::M
              R2B * sizeof(typename C::Acc), (const typename C::Acc*)chunkR, (const typename C::Acc*)chunkA,
              (uint32_t)(nchunks / nsets), wsum, wtot);
   if (P.tables)
-    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, 1, 64, 64 * sizeof(typename C::Acc),
-               wsum, wtot, nsets, log2ks, (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, 1, 128, 0, wsum, wtot, nsets, log2ks,
+               (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);
   else
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets, P.c,
                (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);
