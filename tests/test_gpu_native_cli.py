@@ -63,3 +63,27 @@ def test_native_cli_rejects_bad_files(tmp_path):
     bad.write_bytes(b"nope" + bytes(20))
     out = subprocess.run([exe, "-z", str(bad), "-w", str(bad)], capture_output=True, text=True)
     assert out.returncode != 0 and "not a `zkey` file" in out.stderr
+
+
+def test_snarkjs_laid_out_files_prove_and_verify_python_and_native(ctx, tmp_path):
+    """config-5 stand-in: a `.zkey` / `.wtns` pair laid out the way snarkjs writes them (tests/snarkjs_layout.py:
+    sections out of order, a section 10, (0,0) points on unused wires, dummy public rows; serialised independently of
+    the product's writers) -> parse -> GPU prove -> verify, through the Python host AND the native C++ caller; the
+    proof equals the oracle's for the trivial mask."""
+    from nim_groth16_amd import extractVKey, generateProofWithTrivialMask, verifyProof
+    from nim_groth16_amd.files import exportProof, exportPublicIO, parseWitness, parseZKey
+    from tests.test_files_cpu import _snarkjs_like
+    zpath, wpath, oz, wit, _ = _snarkjs_like(tmp_path)
+    zk, wt = parseZKey(zpath, check=True, ctx=ctx), parseWitness(wpath)       # incl. the on-curve pass over every section
+    pr = generateProofWithTrivialMask(0, False, zk, wt, ctx)
+    ref = o.generate_proof_with_mask(oz, wit, 0, 0)
+    assert (o.g1_from_bytes(pr.pi_a), o.g2_from_bytes(pr.pi_b), o.g1_from_bytes(pr.pi_c)) == (ref.pi_a, ref.pi_b, ref.pi_c)
+    assert o.verify_proof(oz, ref) and verifyProof(extractVKey(zk), pr, ctx)
+    exportProof(str(tmp_path / "py_proof.json"), pr)
+    exportPublicIO(str(tmp_path / "py_public.json"), pr)
+    exe = _build(tmp_path)
+    out = subprocess.run([exe, "-z", zpath, "-w", wpath, "-o", str(tmp_path / "proof.json"), "-i",
+                          str(tmp_path / "public.json"), "-n", "-y"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "verification succeeded" in out.stdout, out.stderr
+    assert open(tmp_path / "proof.json").read() == open(tmp_path / "py_proof.json").read()
+    assert open(tmp_path / "public.json").read() == open(tmp_path / "py_public.json").read()
