@@ -28,7 +28,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dist", choices=["uniform", "circom"], default="uniform",
                     help="circom: 40 %% zero, 30 %% one, 10 %% < 2^16, 20 %% uniform (SURVEY 8d config 2-ii)")
-    ap.add_argument("--only", choices=["all", "ntt"], default="all", help="ntt: NTT + quotient timings only")
+    ap.add_argument("--only", choices=["all", "ntt", "reg"], default="all",
+                    help="ntt: NTT + quotient timings only; reg: registered-set MSMs (the prover's path) + NTT, without "
+                         "the one-shot MSMs (clean per-kernel populations for rocprofv3 --pmc passes)")
     args = ap.parse_args()
     n = 1 << args.log2n
     orc = load_oracle()
@@ -59,9 +61,11 @@ def main():
     t = time.time()
     h1 = ctx.register_points(1, d_p1.data_ptr(), n, device=True)
     print(f"register G1 (tables) {time.time()-t:.3f}s", flush=True)
-    assert ctx.msm_points(h1, d_s.data_ptr(), device=True) == ctx.msm(1, d_s.data_ptr(), d_p1.data_ptr(), n, device=True)
+    reg_only = args.only == "reg"
+    if not reg_only:
+        assert ctx.msm_points(h1, d_s.data_ptr(), device=True) == ctx.msm(1, d_s.data_ptr(), d_p1.data_ptr(), n, device=True)
     for name, fn in [("msm_g1", lambda: ctx.msm(1, d_s.data_ptr(), d_p1.data_ptr(), n, device=True)),
-                     ("msm_g1_registered", lambda: ctx.msm_points(h1, d_s.data_ptr(), device=True))]:
+                     ("msm_g1_registered", lambda: ctx.msm_points(h1, d_s.data_ptr(), device=True))][1 if reg_only else 0:]:
         fn()
         ctx.profile(True)
         ctx.profile_reset()
@@ -80,7 +84,8 @@ def main():
         print(f"   wall without profiling: {(time.time()-t)/args.reps*1e3:.3f} ms/call")
     # correctness spot check vs oracle on a slice
     m = min(n, 1 << 12)
-    assert ctx.msm(1, sb[:32 * m], p1[:64 * m], m) == orc.msm(1, sb[:32 * m], p1[:64 * m])
+    if not reg_only:
+        assert ctx.msm(1, sb[:32 * m], p1[:64 * m], m) == orc.msm(1, sb[:32 * m], p1[:64 * m])
     if args.g2:
         t = time.time()
         p2 = orc.fixed_base(2, kb)
@@ -89,7 +94,8 @@ def main():
         t = time.time()
         h2 = ctx.register_points(2, d_p2.data_ptr(), n, device=True)
         print(f"register G2 (tables) {time.time()-t:.3f}s", flush=True)
-        assert ctx.msm_points(h2, d_s.data_ptr(), device=True) == ctx.msm(2, d_s.data_ptr(), d_p2.data_ptr(), n, device=True)
+        if not reg_only:
+            assert ctx.msm_points(h2, d_s.data_ptr(), device=True) == ctx.msm(2, d_s.data_ptr(), d_p2.data_ptr(), n, device=True)
         fn = lambda: ctx.msm_points(h2, d_s.data_ptr(), device=True)
         fn()
         ctx.profile(True); ctx.profile_reset()

@@ -5,7 +5,7 @@
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc/fetch -o r01 -- \\
       python3 bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc/write -o r01 -- (same command)
-  python3 tools/pmc_traffic.py gpurun_out/pmc profiles/r01_pmc_hbm_traffic_2p20.json
+  python3 tools/pmc_traffic.py gpurun_out/pmc profiles/r01_pmc_hbm_traffic_2p20.json [tag = the -o prefix, default r01]
 
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch (summed over the XCDs here)."""
 import collections
@@ -38,8 +38,9 @@ def load(path, counter):
 
 def main():
     root, out = sys.argv[1], sys.argv[2]
-    f = load(f"{root}/fetch/r01_counter_collection.csv", "FETCH_SIZE")
-    w = load(f"{root}/write/r01_counter_collection.csv", "WRITE_SIZE")
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r01"          # the -o prefix given to rocprofv3
+    f = load(f"{root}/fetch/{tag}_counter_collection.csv", "FETCH_SIZE")
+    w = load(f"{root}/write/{tag}_counter_collection.csv", "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(f) | set(w)):
         fa = sum(f[k]) / len(f[k]) if f.get(k) else 0.0
@@ -50,7 +51,8 @@ def main():
         "workload": "bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline (2^20 full prove), rocprofv3 --pmc "
                     "FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
         "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch; hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024",
-        "calibration": "ntt_pass moves a known 3 x 32 MiB in and out per launch (batched A/B/C): the counters read true "
+        "calibration": "ntt_pass moves a known 3 x 32 MiB in and out per launch (batched A/B/C; round 2: "
+                       "ntt_last_pass_abc reads 3 x 32 MiB and writes 32 MiB): the counters read true "
                        "bytes for this 32-byte-per-lane pattern (no x2 correction).  FETCH_SIZE = read requests x 64 B: "
                        "msm_accum_g1 gathers one aligned 64-B table entry per bucket entry (13.6M x 64 B + 54 MB of "
                        "entry indices = 0.93 GB asked for, 1.18 GB counted); msm_accum_g2 gathers aligned 128-B "
@@ -61,7 +63,7 @@ def main():
         "kernels": kernels,
     }
     json.dump(doc, open(out, "w"), indent=1)
-    for k in ("msm_accum_g1", "msm_accum_g2", "ntt_pass"):
+    for k in ("msm_accum_g1", "msm_accum_g2", "ntt_pass", "ntt_last_pass_abc", "abc_spmv"):
         if k in kernels:
             print(k, kernels[k])
 

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include <string>
+#include <algorithm>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
@@ -17,8 +18,14 @@ constexpr int UNROLL = 4;   // x CHAINS instructions per loop iteration
 enum Op { ADD_U32, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24,
           FMA_F64, ADDC_PAIR, FMA_F32, MAD_U32_U16, LSHL_ADD_U64, MUL_U32_U24, MAD_U64_DEP, LSHR_B64, ALIGNBIT, AND_B32, MAD_U64_SGPR, ADD3_U32, LSHL_OR };
 
+// Every wave stamps the shader clock (s_memtime: one tick per shader cycle) and the constant 100 MHz counter
+// (s_memrealtime) around its loop; wave 0 of each workgroup stores the two deltas.  The host takes the median:
+//   cycles per wave-instruction per SIMD = d_memtime / (waves per SIMD * instructions per wave)      -- REAL cycles
+//   in-kernel clock                      = d_memtime / d_memrealtime * 100 MHz
+// (round 1 converted event time to cycles at an assumed 2.4 GHz, which the chip does not hold under this load).
 template <int OP>
-__global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed) {
+__global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed, unsigned long long* stamps) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   unsigned a[CHAINS], b[CHAINS];
   unsigned long long w[CHAINS];
   double d[CHAINS];
@@ -80,25 +87,52 @@ __global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed
   unsigned r = 0;
   for (int i = 0; i < CHAINS; ++i) r ^= a[i] ^ b[i] ^ (unsigned)w[i] ^ (unsigned)(w[i] >> 32) ^ (unsigned)__double_as_longlong(d[i]);
   if (r == 0x12345678u) out[0] = r;   // keep live
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (stamps && threadIdx.x == 0) {   // stamp buffer of its own: nothing else reads it
+    stamps[2 * blockIdx.x] = t1 - t0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
+static unsigned long long* g_stamps = nullptr;
+static std::vector<unsigned long long> h_stamps;
+static double median(std::vector<double> v) {
+  std::sort(v.begin(), v.end());
+  return v[v.size() / 2];
 }
 
 template <int OP>
 double run(const char* name, int blocks, int iters, unsigned* out, int instr_per = 1) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  k<OP><<<blocks, 256>>>(out, 16, 7u);
+  k<OP><<<blocks, 256>>>(out, 16, 7u, nullptr);
   CHECK(hipDeviceSynchronize());
   float best = 1e30f;
+  double cyc = 0, clk = 0;
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipEventRecord(e0));
-    k<OP><<<blocks, 256>>>(out, iters, 7u + rep);
+    k<OP><<<blocks, 256>>>(out, iters, 7u + rep, g_stamps);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
-    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) {
+      best = ms;
+      CHECK(hipMemcpy(h_stamps.data(), g_stamps, (size_t)blocks * 16, hipMemcpyDeviceToHost));
+      std::vector<double> dt, ck;
+      for (int b = 0; b < blocks; ++b) {
+        dt.push_back((double)h_stamps[2 * b]);
+        ck.push_back((double)h_stamps[2 * b] / (double)h_stamps[2 * b + 1] * 0.1);   // GHz
+      }
+      cyc = median(dt);
+      clk = median(ck);
+    }
   }
+  const double waves_per_simd = (double)blocks * 4 / 1024.0;
+  const double per_wave = (double)iters * UNROLL * CHAINS * instr_per;
   double waves = (double)blocks * 4;
-  double winstr = waves * iters * UNROLL * CHAINS * instr_per;
+  double winstr = waves * per_wave;
   double rate = winstr / (best * 1e-3);      // wave-instr / s chip-wide
-  printf("%-16s blocks=%5d  %8.3f ms  %10.3f Gwinstr/s  => %6.2f cyc/winstr/SIMD @2.4GHz (1024 SIMDs)\n",
-         name, blocks, best, rate * 1e-9, 1024.0 * 2.4e9 / rate);
+  printf("%-16s blocks=%5d  %8.3f ms  %10.3f Gwinstr/s  => %6.2f cycles/winstr/SIMD (s_memtime; in-kernel clock %.3f GHz)\n",
+         name, blocks, best, rate * 1e-9, cyc / (waves_per_simd * per_wave), clk);
   return rate;
 }
 
@@ -106,6 +140,8 @@ int main() {
   unsigned* out; CHECK(hipMalloc(&out, 4));
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   printf("device %s CUs=%d clock=%d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
+  CHECK(hipMalloc(&g_stamps, 4096 * 16));
+  h_stamps.resize(4096 * 2);
   for (int pass = 0; pass < 2; ++pass) {
     // pass 0: 8 waves/SIMD (2048 blocks of 4 waves on 256 CUs = 8 blocks/CU);  pass 1: 1 wave/SIMD
     int blocks = pass == 0 ? 256 * 8 : 256;

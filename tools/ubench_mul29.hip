@@ -3,9 +3,19 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
+#include <algorithm>
 #include "../nim_groth16_amd/csrc/ff.cuh"
 #include "../nim_groth16_amd/csrc/ff29.cuh"
 using namespace g16;
+// real cycles: every wave brackets its loop with s_memtime (shader cycles) / s_memrealtime (100 MHz); wave 0 of each
+// workgroup stores the deltas into a buffer nothing else reads.  cycles per wave-mul per SIMD =
+// d_memtime / (resident waves per SIMD * multiplications per wave).
+__device__ unsigned long long* g_stamp_ptr;
+#define STAMP_BEGIN const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
+#define STAMP_END do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();            \
+    if (threadIdx.x == 0 && g_stamp_ptr) { g_stamp_ptr[2 * blockIdx.x] = t1_ - t0_; g_stamp_ptr[2 * blockIdx.x + 1] = r1_ - r0_; } } while (0)
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
@@ -13,46 +23,67 @@ template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k32(u256* io, int iters) {
   u256 x = io[threadIdx.x & 63], y = io[64 + (threadIdx.x & 63)];
   x.v[0] ^= blockIdx.x; 
+  STAMP_BEGIN
   for (int i = 0; i < iters; ++i) { x = Fp::mul(x, y); y = Fp::mul(y, x); }
+  STAMP_END;
   if (x.v[0] == 0x12345u) io[0] = y;
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k29(fe29* io, int iters) {
   fe29 x = io[threadIdx.x & 63], y = io[64 + (threadIdx.x & 63)];
   x.v[0] ^= blockIdx.x & 0xff;
+  STAMP_BEGIN
   for (int i = 0; i < iters; ++i) { x = Fp29::mul(x, y); y = Fp29::mul(y, x); }
+  STAMP_END;
   if (x.v[0] == 0x12345u) io[0] = y;
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k29d(fe29* io, int iters) {   // dot product (ab+cd)/R
   fe29 x = io[threadIdx.x & 63], y = io[64 + (threadIdx.x & 63)], z = io[(threadIdx.x + 7) & 63], w = io[(threadIdx.x + 9) & 63];
   x.v[0] ^= blockIdx.x & 0xff;
+  STAMP_BEGIN
   for (int i = 0; i < iters; ++i) { x = Fp29::dot2(x, y, z, w); z = Fp29::dot2(z, w, x, y); }   // all operands loop-variant
+  STAMP_END;
   if (x.v[0] == 0x12345u) io[0] = z;
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k29s(fe29* io, int iters) {   // squaring
   fe29 x = io[threadIdx.x & 63], y = io[64 + (threadIdx.x & 63)];
   x.v[0] ^= blockIdx.x & 0xff;
+  STAMP_BEGIN
   for (int i = 0; i < iters; ++i) { x = Fp29::sqr(y); y = Fp29::sqr(x); }
+  STAMP_END;
   if (x.v[0] == 0x12345u) io[0] = y;
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k32d(u256* io, int iters) {
   u256 x = io[threadIdx.x & 63], y = io[64 + (threadIdx.x & 63)], z = io[(threadIdx.x + 7) & 63], w = io[(threadIdx.x + 9) & 63];
   x.v[0] ^= blockIdx.x;
+  STAMP_BEGIN
   for (int i = 0; i < iters; ++i) { x = Fp::mul2(x, y, z, w); z = Fp::mul2(z, w, x, y); }
+  STAMP_END;
   if (x.v[0] == 0x12345u) io[0] = y;
 }
 
+static unsigned long long* d_stamps = nullptr;
+static double g_cyc = 0, g_clk = 0;
 template <class F>
-double timeit(F launch) {
+double timeit(F launch, int blocks) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   launch(); CHECK(hipDeviceSynchronize());
   float best = 1e30f;
+  std::vector<unsigned long long> h((size_t)blocks * 2);
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
-    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) {
+      best = ms;
+      CHECK(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> dt, ck;
+      for (int b = 0; b < blocks; ++b) { dt.push_back((double)h[2 * b]); ck.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1); }
+      std::sort(dt.begin(), dt.end()); std::sort(ck.begin(), ck.end());
+      g_cyc = dt[dt.size() / 2]; g_clk = ck[ck.size() / 2];
+    }
   }
   return best;
 }
@@ -66,17 +97,19 @@ int main() {
     CHECK(hipMemcpy(buf, h, sizeof(h), hipMemcpyHostToDevice));
   }
   const int iters = 2000, blocks = 4096;
+  CHECK(hipMalloc(&d_stamps, (size_t)blocks * 16));
+  CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_ptr), &d_stamps, sizeof(d_stamps)));
   const double muls = 2.0 * iters * blocks * 256;
-  auto rep = [&](const char* name, double ms, double per) {
-    printf("%-28s %8.3f ms  %7.2f Gmul/s  (%.0f SIMD-cycles/wave-mul @2.4GHz)\n", name, ms, per * muls / ms / 1e6,
-           ms * 1e-3 * 2.4e9 * 1024 / (per * muls / 64));
+  auto rep = [&](const char* name, double ms, int waves) {
+    printf("%-28s %8.3f ms  %7.2f Gmul/s  %7.0f cycles/wave-mul/SIMD (s_memtime; in-kernel clock %.3f GHz)\n", name, ms,
+           muls / ms / 1e6, g_cyc / (waves * 2.0 * iters), g_clk);
   };
-  rep("8x32 mul   (4 waves/SIMD)", timeit([&] { k32<4><<<blocks, 256>>>((u256*)buf, iters); }), 1);
-  rep("9x29 mul   (4 waves/SIMD)", timeit([&] { k29<4><<<blocks, 256>>>((fe29*)buf, iters); }), 1);
-  rep("8x32 mul   (2 waves/SIMD)", timeit([&] { k32<2><<<blocks, 256>>>((u256*)buf, iters); }), 1);
-  rep("9x29 mul   (2 waves/SIMD)", timeit([&] { k29<2><<<blocks, 256>>>((fe29*)buf, iters); }), 1);
-  rep("8x32 mul2  (4 waves/SIMD)", timeit([&] { k32d<4><<<blocks, 256>>>((u256*)buf, iters); }), 1);
-  rep("9x29 dot2  (4 waves/SIMD)", timeit([&] { k29d<4><<<blocks, 256>>>((fe29*)buf, iters); }), 1);
-  rep("9x29 sqr   (4 waves/SIMD)", timeit([&] { k29s<4><<<blocks, 256>>>((fe29*)buf, iters); }), 1);
+  rep("8x32 mul   (4 waves/SIMD)", timeit([&] { k32<4><<<blocks, 256>>>((u256*)buf, iters); }, blocks), 4);
+  rep("9x29 mul   (4 waves/SIMD)", timeit([&] { k29<4><<<blocks, 256>>>((fe29*)buf, iters); }, blocks), 4);
+  rep("8x32 mul   (2 waves/SIMD)", timeit([&] { k32<2><<<blocks, 256>>>((u256*)buf, iters); }, blocks), 2);
+  rep("9x29 mul   (2 waves/SIMD)", timeit([&] { k29<2><<<blocks, 256>>>((fe29*)buf, iters); }, blocks), 2);
+  rep("8x32 mul2  (4 waves/SIMD)", timeit([&] { k32d<4><<<blocks, 256>>>((u256*)buf, iters); }, blocks), 4);
+  rep("9x29 dot2  (4 waves/SIMD)", timeit([&] { k29d<4><<<blocks, 256>>>((fe29*)buf, iters); }, blocks), 4);
+  rep("9x29 sqr   (4 waves/SIMD)", timeit([&] { k29s<4><<<blocks, 256>>>((fe29*)buf, iters); }, blocks), 4);
   return 0;
 }
