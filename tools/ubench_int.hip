@@ -19,9 +19,11 @@ enum Op { ADD_U32, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_
           FMA_F64, ADDC_PAIR, FMA_F32, MAD_U32_U16, LSHL_ADD_U64, MUL_U32_U24, MAD_U64_DEP, LSHR_B64, ALIGNBIT, AND_B32, MAD_U64_SGPR, ADD3_U32, LSHL_OR };
 
 // Every wave stamps the shader clock (s_memtime: one tick per shader cycle) and the constant 100 MHz counter
-// (s_memrealtime) around its loop; wave 0 of each workgroup stores the two deltas.  The host takes the median:
-//   cycles per wave-instruction per SIMD = d_memtime / (waves per SIMD * instructions per wave)      -- REAL cycles
-//   in-kernel clock                      = d_memtime / d_memrealtime * 100 MHz
+// (s_memrealtime) around its loop; wave 0 of each workgroup stores them.  No clock is assumed anywhere:
+//   in-kernel clock                      = median over workgroups of d_memtime / d_memrealtime * 100 MHz
+//   wall time of the launch              = (latest end stamp - earliest start stamp) of s_memrealtime
+//   cycles per wave-instruction per SIMD = wall * clock * 1024 SIMDs / wave-instructions issued      -- REAL cycles
+// (occupancy-independent: the 8-waves case need not have all its workgroups resident at once)
 // (round 1 converted event time to cycles at an assumed 2.4 GHz, which the chip does not hold under this load).
 template <int OP>
 __global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed, unsigned long long* stamps) {
@@ -90,8 +92,10 @@ __global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   if (stamps && threadIdx.x == 0) {   // stamp buffer of its own: nothing else reads it
-    stamps[2 * blockIdx.x] = t1 - t0;
-    stamps[2 * blockIdx.x + 1] = r1 - r0;
+    stamps[4 * blockIdx.x] = t1 - t0;
+    stamps[4 * blockIdx.x + 1] = r1 - r0;
+    stamps[4 * blockIdx.x + 2] = r0;     // absolute 100 MHz stamps: the launch's wall time as seen from inside
+    stamps[4 * blockIdx.x + 3] = r1;
   }
 }
 
@@ -116,23 +120,24 @@ double run(const char* name, int blocks, int iters, unsigned* out, int instr_per
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) {
       best = ms;
-      CHECK(hipMemcpy(h_stamps.data(), g_stamps, (size_t)blocks * 16, hipMemcpyDeviceToHost));
-      std::vector<double> dt, ck;
+      CHECK(hipMemcpy(h_stamps.data(), g_stamps, (size_t)blocks * 32, hipMemcpyDeviceToHost));
+      std::vector<double> ck;
+      unsigned long long first = ~0ull, last = 0;
       for (int b = 0; b < blocks; ++b) {
-        dt.push_back((double)h_stamps[2 * b]);
-        ck.push_back((double)h_stamps[2 * b] / (double)h_stamps[2 * b + 1] * 0.1);   // GHz
+        ck.push_back((double)h_stamps[4 * b] / (double)h_stamps[4 * b + 1] * 0.1);   // GHz
+        first = std::min(first, h_stamps[4 * b + 2]);
+        last = std::max(last, h_stamps[4 * b + 3]);
       }
-      cyc = median(dt);
       clk = median(ck);
+      cyc = (double)(last - first) * 1e-8 * clk * 1e9;    // wall cycles of the launch at the in-kernel clock
     }
   }
-  const double waves_per_simd = (double)blocks * 4 / 1024.0;
   const double per_wave = (double)iters * UNROLL * CHAINS * instr_per;
   double waves = (double)blocks * 4;
   double winstr = waves * per_wave;
   double rate = winstr / (best * 1e-3);      // wave-instr / s chip-wide
   printf("%-16s blocks=%5d  %8.3f ms  %10.3f Gwinstr/s  => %6.2f cycles/winstr/SIMD (s_memtime; in-kernel clock %.3f GHz)\n",
-         name, blocks, best, rate * 1e-9, cyc / (waves_per_simd * per_wave), clk);
+         name, blocks, best, rate * 1e-9, cyc * 1024.0 / winstr, clk);
   return rate;
 }
 
@@ -140,8 +145,8 @@ int main() {
   unsigned* out; CHECK(hipMalloc(&out, 4));
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   printf("device %s CUs=%d clock=%d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
-  CHECK(hipMalloc(&g_stamps, 4096 * 16));
-  h_stamps.resize(4096 * 2);
+  CHECK(hipMalloc(&g_stamps, 4096 * 32));
+  h_stamps.resize(4096 * 4);
   for (int pass = 0; pass < 2; ++pass) {
     // pass 0: 8 waves/SIMD (2048 blocks of 4 waves on 256 CUs = 8 blocks/CU);  pass 1: 1 wave/SIMD
     int blocks = pass == 0 ? 256 * 8 : 256;

@@ -9,13 +9,14 @@
 #include "../nim_groth16_amd/csrc/ff29.cuh"
 using namespace g16;
 // real cycles: every wave brackets its loop with s_memtime (shader cycles) / s_memrealtime (100 MHz); wave 0 of each
-// workgroup stores the deltas into a buffer nothing else reads.  cycles per wave-mul per SIMD =
-// d_memtime / (resident waves per SIMD * multiplications per wave).
+// workgroup stores them into a buffer nothing else reads.  clock = median d_memtime / d_memrealtime * 100 MHz;
+// wall = latest end - earliest start of s_memrealtime; cycles per wave-mul per SIMD = wall * clock * 1024 / wave-muls.
 __device__ unsigned long long* g_stamp_ptr;
 #define STAMP_BEGIN const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
 #define STAMP_END do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
     const unsigned long long t1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();            \
-    if (threadIdx.x == 0 && g_stamp_ptr) { g_stamp_ptr[2 * blockIdx.x] = t1_ - t0_; g_stamp_ptr[2 * blockIdx.x + 1] = r1_ - r0_; } } while (0)
+    if (threadIdx.x == 0 && g_stamp_ptr) { g_stamp_ptr[4 * blockIdx.x] = t1_ - t0_; g_stamp_ptr[4 * blockIdx.x + 1] = r1_ - r0_;  \
+      g_stamp_ptr[4 * blockIdx.x + 2] = r0_; g_stamp_ptr[4 * blockIdx.x + 3] = r1_; } } while (0)
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
@@ -72,17 +73,23 @@ double timeit(F launch, int blocks) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   launch(); CHECK(hipDeviceSynchronize());
   float best = 1e30f;
-  std::vector<unsigned long long> h((size_t)blocks * 2);
+  std::vector<unsigned long long> h((size_t)blocks * 4);
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) {
       best = ms;
       CHECK(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
-      std::vector<double> dt, ck;
-      for (int b = 0; b < blocks; ++b) { dt.push_back((double)h[2 * b]); ck.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1); }
-      std::sort(dt.begin(), dt.end()); std::sort(ck.begin(), ck.end());
-      g_cyc = dt[dt.size() / 2]; g_clk = ck[ck.size() / 2];
+      std::vector<double> ck;
+      unsigned long long first = ~0ull, last = 0;
+      for (int b = 0; b < blocks; ++b) {
+        ck.push_back((double)h[4 * b] / (double)h[4 * b + 1] * 0.1);
+        first = std::min(first, h[4 * b + 2]);
+        last = std::max(last, h[4 * b + 3]);
+      }
+      std::sort(ck.begin(), ck.end());
+      g_clk = ck[ck.size() / 2];
+      g_cyc = (double)(last - first) * 1e-8 * g_clk * 1e9;   // wall cycles of the launch
     }
   }
   return best;
@@ -97,12 +104,12 @@ int main() {
     CHECK(hipMemcpy(buf, h, sizeof(h), hipMemcpyHostToDevice));
   }
   const int iters = 2000, blocks = 4096;
-  CHECK(hipMalloc(&d_stamps, (size_t)blocks * 16));
+  CHECK(hipMalloc(&d_stamps, (size_t)blocks * 32));
   CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_ptr), &d_stamps, sizeof(d_stamps)));
   const double muls = 2.0 * iters * blocks * 256;
   auto rep = [&](const char* name, double ms, int waves) {
     printf("%-28s %8.3f ms  %7.2f Gmul/s  %7.0f cycles/wave-mul/SIMD (s_memtime; in-kernel clock %.3f GHz)\n", name, ms,
-           muls / ms / 1e6, g_cyc / (waves * 2.0 * iters), g_clk);
+           muls / ms / 1e6, g_cyc * 1024.0 / (muls / 64.0), g_clk);
   };
   rep("8x32 mul   (4 waves/SIMD)", timeit([&] { k32<4><<<blocks, 256>>>((u256*)buf, iters); }, blocks), 4);
   rep("9x29 mul   (4 waves/SIMD)", timeit([&] { k29<4><<<blocks, 256>>>((fe29*)buf, iters); }, blocks), 4);
