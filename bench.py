@@ -57,6 +57,9 @@ def parse_args(argv=None):
                          "accumulation")
     ap.add_argument("--witness", choices=["host", "hbm"], default="host",
                     help="where the timed steps take the witness from (host = pinned memory, .wtns layout)")
+    ap.add_argument("--quotient", choices=["tasks", "replicated"], default="tasks",
+                    help="shard mode: the three coset pipelines of the quotient on three different ranks + three "
+                         "scatters of the slices (tasks), or recomputed by every rank (replicated)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduction plumbing only (gloo, no GPU, no proofs): what the CPU test "
                          "of the multi-rank launch path runs; prints a line with value 0 and dry_run true")
@@ -154,19 +157,15 @@ def main(argv=None):
     torch.cuda.synchronize()
 
     if shard:
-        from nim_groth16_amd._lib import PARTIALS_BYTES
-        mine = torch.empty(PARTIALS_BYTES, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(world * PARTIALS_BYTES, dtype=torch.uint8, device=coll_dev)
+        # one proof over all ranks (nim_groth16_amd/distributed.py): sharded MSMs, the three coset pipelines of the
+        # quotient on three different ranks (--quotient tasks) or replicated on all of them (--quotient replicated),
+        # then one all-gather of the 768-byte partial records
+        from nim_groth16_amd.distributed import ShardedProver
+        sp = ShardedProver(zkey, rank, world, ctx=ctx, quotient=args.quotient, pkey=pkey)
 
         def step(i, lane=0, hbm=False):
             w = (d_w if hbm else h_w)[i % NWITNESS]
-            pkey.prove_partials(w.data_ptr(), mont=False, device=hbm, out=mine.data_ptr())
-            if coll_dev == "cuda":      # one RCCL all-gather of 768-byte records per proof
-                dist.all_gather_into_tensor(gathered, mine)
-                torch.cuda.current_stream().synchronize()
-                return pkey.prove_combine(gathered.data_ptr(), world, rb, sb, device=True)
-            dist.all_gather_into_tensor(gathered, mine.cpu())
-            return pkey.prove_combine(gathered.numpy().tobytes(), world, rb, sb)
+            return sp.prove_raw(w.data_ptr(), False, rb, sb, device=hbm)
     else:
         def step(i, lane=0, hbm=False):
             w = (d_w if hbm else h_w)[i % NWITNESS]
@@ -345,7 +344,7 @@ def main(argv=None):
                                    f" ({inflight} proofs in flight per GPU, one shared key)"
                                    if not shard else
                                    f"BN254 2^{args.log2n}-constraint synthetic R1CS, ONE proof per step, MSMs point-sharded "
-                                   f"over {world} GPUs + all-gather of partials",
+                                   f"over {world} GPUs + all-gather of partials, quotient {args.quotient}",
                        "mode": "shard" if shard else "replica", "nvars": zkey.header.nvars,
                        "domain_log2": args.log2n,
                        "inputs": f"proving key resident in HBM, witness from {where}, rotating over {NWITNESS} "

@@ -187,6 +187,22 @@ int32_t g16_prove(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32
 int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, void* out_partials);
 int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* key, const void* partials, size_t count, uint32_t flags,
                           const void* mask_r, const void* mask_s, g16_proof* out);
+/* Sharded proof with a TASK-PARALLEL quotient (snarkjs-flavour keys): the three coset pipelines that
+ * computeSnarkjsScalarCoeffs runs as three Taskpool tasks (prover.nim:167-169) live on three different ranks instead
+ * of being replicated on all of them.
+ *  g16_prove_partials_begin: uploads the witness, launches this key's four witness MSMs (they keep running after
+ *      the call returns) and computes the coset vectors named by task_mask (bit 0: A, 1: B, 2: C) -- buildABC +
+ *      shiftEvalDomain (prover.nim:56-73, 109-113) -- into d_task_out: domainSize Fr per set bit, in ascending bit
+ *      order, device memory.  flags as for g16_prove_partials.  task_mask = 0: this rank owns no pipeline.
+ *  (caller: every rank receives the [h_lo, h_hi) slices of the three coset vectors, h = domainSize * rank / count,
+ *      from the ranks that own them -- three scatters; 32 * domainSize / count bytes per slice)
+ *  g16_prove_partials_end: forms this rank's H scalars A1*B1 - C1 from the received slices (device pointers,
+ *      h_hi - h_lo Fr each; prover.nim:175-176), runs the H MSM over them, joins the witness MSMs and writes the
+ *      768-byte record exactly like g16_prove_partials.  Then g16_prove_combine as usual. */
+int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags,
+                                 uint32_t task_mask, void* d_task_out);
+int32_t g16_prove_partials_end(g16_ctx* ctx, const g16_pkey* key, const void* d_a1_slice, const void* d_b1_slice,
+                               const void* d_c1_slice, uint32_t flags, void* out_partials);
 /* buildABC alone (prover.nim:56-73): out_abc = Az | Bz | Cz, 3 * domainSize Fr (Montgomery), host memory */
 int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, void* out_abc);
 

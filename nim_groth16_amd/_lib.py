@@ -21,6 +21,7 @@ SYMBOLS = [
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_info", "g16_msm_points",
     "g16_points_check_g1", "g16_points_check_g2", "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
     "g16_pkey_destroy", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
+    "g16_prove_partials_begin", "g16_prove_partials_end",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
     "g16_vkey_create", "g16_vkey_destroy", "g16_verify", "g16_pairing",
 ]
@@ -111,6 +112,8 @@ def load_library():
     lib.g16_build_abc.argtypes = [vp, vp, vp, u32, vp]
     lib.g16_prove_partials.argtypes = [vp, vp, vp, u32, vp]
     lib.g16_prove_combine.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp]
+    lib.g16_prove_partials_begin.argtypes = [vp, vp, vp, u32, u32, vp]
+    lib.g16_prove_partials_end.argtypes = [vp, vp, vp, vp, vp, u32, vp]
     lib.g16_ntt_fr.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_ntt_fr_dev.argtypes = [vp, vp, vp, u32, i32]
     lib.g16_vkey_create.argtypes = [vp, ctypes.POINTER(VkeyDesc), ctypes.POINTER(vp)]
@@ -323,6 +326,28 @@ class ProvingKey:
             return None
         buf = ctypes.create_string_buffer(PARTIALS_BYTES)
         c._check(c._lib.g16_prove_partials(c._h, self._h, _buf(witness), flags, buf))
+        return buf.raw
+
+    def prove_partials_begin(self, witness, task_mask: int, task_out=None, mont: bool = True, device: bool = False,
+                             ctx=None):
+        """first half of a sharded proof with a task-parallel quotient: launches this key's witness MSMs and writes
+        the coset vectors named by task_mask (bit 0: A, 1: B, 2: C) to the device pointer task_out"""
+        c = ctx or self.ctx
+        self._check_len(witness)
+        flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
+        c._check(c._lib.g16_prove_partials_begin(c._h, self._h, _buf(witness), flags, task_mask,
+                                                 _buf(task_out) if task_out is not None else None))
+
+    def prove_partials_end(self, a1, b1, c1, out=None, ctx=None):
+        """second half: a1 / b1 / c1 = device pointers to this key's [h_lo, h_hi) slices of the three coset vectors
+        (None for an empty range); -> the 768-byte record (or written to the device pointer `out`)"""
+        c = ctx or self.ctx
+        ptr = lambda x: _buf(x) if x is not None else None          # noqa: E731
+        if out is not None:
+            c._check(c._lib.g16_prove_partials_end(c._h, self._h, ptr(a1), ptr(b1), ptr(c1), OUT_DEVICE, _buf(out)))
+            return None
+        buf = ctypes.create_string_buffer(PARTIALS_BYTES)
+        c._check(c._lib.g16_prove_partials_end(c._h, self._h, ptr(a1), ptr(b1), ptr(c1), 0, buf))
         return buf.raw
 
     def prove_combine(self, partials, count: int, r: bytes = None, s: bytes = None, device: bool = False, ctx=None):

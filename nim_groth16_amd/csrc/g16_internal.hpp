@@ -74,6 +74,7 @@ struct g16_ctx {
   Buf prove;     // per-proof scalars: witness, Az|Bz|Cz, qs
   Buf fb_table[2];  // fixed-base tables of gen1 / gen2
   bool fb_ready[2] = {false, false};
+  const void* shard_begun = nullptr;   // key of a g16_prove_partials_begin that still awaits its _end
   uint32_t tw_log2n = 0xffffffffu;
   uint32_t coset_log2n[2] = {0xffffffffu, 0xffffffffu};
   // profiling
@@ -208,3 +209,8 @@ int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t lo
 // d_a, d_b, d_c, d_out: n elements each (device); inputs are not modified
 int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, uint32_t log2n,
                             int flavour, void* d_out);
+// one coset pipeline (shiftEvalDomain, prover.nim:109-113) and the pointwise step on separately held slices: the
+// pieces of the task-parallel quotient of a sharded proof
+int32_t g16_coset_pipeline_device(g16_ctx* ctx, const void* d_in, uint32_t log2n, void* d_out);
+int32_t g16_abc_pointwise_device(g16_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, size_t count,
+                                 void* d_out);

@@ -226,4 +226,15 @@ static __global__ void __launch_bounds__(256) ntt_make_coset_table(u256* __restr
   tab[i] = Fr::mul(fr_pow_u32(eta, e), ninv);
 }
 
+// ys[j] = A1[j]*B1[j] - C1[j]   (prover.nim:175-176) on separately held vectors: the multi-GPU task-parallel quotient
+// (one coset pipeline per rank) forms its slice of the H scalars from three received slices.  The single-GPU path
+// has this step fused into ntt_last_pass_abc.
+static __global__ void __launch_bounds__(256) fr_abc_pointwise(const u256* __restrict__ a, const u256* __restrict__ b,
+                                                        const u256* __restrict__ c, u256* __restrict__ out,
+                                                        uint32_t n) {
+  uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  out[j] = Fr::sub(Fr::mul(a[j], b[j]), c[j]);
+}
+
 }  // namespace g16

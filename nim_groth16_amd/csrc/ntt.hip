@@ -148,3 +148,29 @@ int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, cons
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
+
+// shiftEvalDomain of ONE vector (prover.nim:109-113): values on H -> values on the coset eta*H.  The unit of the
+// task-parallel quotient of a sharded proof: the reference runs the A, B, C pipelines as three Taskpool tasks
+// (prover.nim:167-169); across GPUs each task lives on its own rank.  d_in is not modified; d_out != d_in.
+int32_t g16_coset_pipeline_device(g16_ctx* ctx, const void* d_in, uint32_t log2n, void* d_out) {
+  if (log2n > 27) {
+    ctx->err = "quotient needs the 2n domain: log2n <= 27";
+    return G16_EINVAL;
+  }
+  const size_t n = size_t(1) << log2n;
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->quot, 4 * n * 32))) return rc;
+  if ((rc = ensure_coset(ctx, log2n, 0))) return rc;
+  u256* X = (u256*)ctx->quot.p;
+  if ((rc = ntt_batched(ctx, (const u256*)d_in, n, X, n, 1, log2n, 1, (const u256*)ctx->coset[0].p))) return rc;
+  return ntt_batched(ctx, X, n, (u256*)d_out, n, 1, log2n, 0, nullptr);
+}
+
+int32_t g16_abc_pointwise_device(g16_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, size_t count,
+                                 void* d_out) {
+  if (count)
+    KLAUNCH(ctx, "fr_abc_pointwise", fr_abc_pointwise, (uint32_t)((count + 255) / 256), 256, 0, (const u256*)d_a,
+            (const u256*)d_b, (const u256*)d_c, (u256*)d_out, (uint32_t)count);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}

@@ -270,61 +270,160 @@ extern "C" int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* k, const voi
   return rc;
 }
 
-static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
-                                   void* out_partials) {
+// ---- the pieces of a proof's launch sequence ---------------------------------------------------------------
+struct ProveBufs {
+  u256 *d_w, *d_abc, *d_qs;
+  char* slots;
+};
+static int32_t prove_bufs(g16_ctx* ctx, const g16_pkey* k, ProveBufs& b) {
   const size_t n = size_t(1) << k->log2n;
-  const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
   int32_t rc;
   if ((rc = ensure(ctx, ctx->prove, ((size_t)k->nvars + 4 * n) * 32))) return rc;
   if ((rc = ensure(ctx, ctx->stage_o, 2048))) return rc;
-  u256* d_w = (u256*)ctx->prove.p;
-  u256* d_abc = d_w + k->nvars;
-  u256* d_qs = d_abc + 3 * n;
-  HIPCHK(ctx, hipMemcpyAsync(d_w, witness, (size_t)k->nvars * 32,
+  b.d_w = (u256*)ctx->prove.p;
+  b.d_abc = b.d_w + k->nvars;
+  b.d_qs = b.d_abc + 3 * n;
+  b.slots = (char*)ctx->stage_o.p;
+  return G16_OK;
+}
+
+// witness -> HBM, then the four MSMs that consume it (A1, B1, B2, C1: prover.nim:282, 288, 294, 302) on the lane
+// streams.  The witness' signed-digit bucket arrangement is computed once (lane 0) and shared; the four
+// accumulate/reduce pipelines run on four streams so that their latency-bound tails overlap with the other
+// pipelines' accumulation.  Nothing is waited for here.
+static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
+                                   const ProveBufs& b) {
+  const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
+  int32_t rc;
+  HIPCHK(ctx, hipMemcpyAsync(b.d_w, witness, (size_t)k->nvars * 32,
                              (flags & G16_SCALARS_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                              ctx->stream));
-  char* slots = (char*)ctx->stage_o.p;
   hipStream_t M = ctx->stream;
-  HIPCHK(ctx, hipMemsetAsync(slots, 0, PART_BYTES, M));   // empty range -> XYZZ infinity (all zero)
-  HIPCHK(ctx, hipEventRecord(ctx->ev_a, M));              // witness resident
+  HIPCHK(ctx, hipMemsetAsync(b.slots, 0, PART_BYTES, M));   // empty range -> XYZZ infinity (all zero)
+  HIPCHK(ctx, hipEventRecord(ctx->ev_a, M));                // witness resident
   const uint32_t wflags = wit_mont ? G16_SCALARS_MONT : 0u;
-  const size_t nw = k->w_hi - k->w_lo, nh = k->h_hi - k->h_lo;
-  // The witness feeds four MSMs (A1, B1, B2, C1: prover.nim:282, 288, 294, 302): its signed-digit bucket
-  // arrangement is computed once (lane 0) and shared; the four accumulate/reduce pipelines then run on four
-  // streams so that their latency-bound tails overlap with the other pipelines' accumulation.
+  const size_t nw = k->w_hi - k->w_lo;
   if (nw) {
     g16_ctx::MsmLane* L = ctx->lane;
     HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
-    if ((rc = g16_msm_sort(ctx, L[0].stream, d_w + k->w_lo, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
+    if ((rc = g16_msm_sort(ctx, L[0].stream, b.d_w + k->w_lo, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
     for (int i = 1; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, ctx->ev_b, 0));
-    if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, ctx->sort[0], k->B2->d_tables, nullptr, slots + PART_B2)))
+    if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, ctx->sort[0], k->B2->d_tables, nullptr, b.slots + PART_B2)))
       return rc;
     // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES (read once per process, g16_env) reassigns them
     const int la = g16_env().g1_lanes[0], lb = g16_env().g1_lanes[1], lc = g16_env().g1_lanes[2];
-    if ((rc = g16_msm_reduce_g1(ctx, L[la].stream, L[la].acc, ctx->sort[0], k->A1->d_tables, nullptr, slots + PART_A)))
+    if ((rc = g16_msm_reduce_g1(ctx, L[la].stream, L[la].acc, ctx->sort[0], k->A1->d_tables, nullptr, b.slots + PART_A)))
       return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[lb].stream, L[lb].acc, ctx->sort[0], k->B1->d_tables, nullptr, slots + PART_B1)))
+    if ((rc = g16_msm_reduce_g1(ctx, L[lb].stream, L[lb].acc, ctx->sort[0], k->B1->d_tables, nullptr, b.slots + PART_B1)))
       return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[lc].stream, L[lc].acc, ctx->sort[0], k->C1->d_tables, nullptr, slots + PART_C)))
+    if ((rc = g16_msm_reduce_g1(ctx, L[lc].stream, L[lc].acc, ctx->sort[0], k->C1->d_tables, nullptr, b.slots + PART_C)))
       return rc;
     for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipEventRecord(L[i].done, L[i].stream));
   }
-  // buildABC + quotient (prover.nim:244-260) on the main stream, concurrently with the witness MSMs;
-  // replicated on every rank of a sharded proof (~1 ms, no exchange); then the H MSM (prover.nim:301)
-  if ((rc = build_abc_device(ctx, k, d_w, wit_mont, d_abc))) return rc;
-  if ((rc = g16_quotient_device(ctx, d_abc, d_abc + n, d_abc + 2 * n, k->log2n, (int)k->flavour, d_qs))) return rc;
+  return G16_OK;
+}
+
+// the H MSM over this key's domain range (prover.nim:301) on the main stream, then join the lanes and hand out the
+// five partials.  d_qs_slice: the H scalars of [h_lo, h_hi), Montgomery.
+static int32_t launch_h_and_collect(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice, uint32_t flags,
+                                    const ProveBufs& b, void* out_partials) {
+  int32_t rc;
+  hipStream_t M = ctx->stream;
+  const size_t nw = k->w_hi - k->w_lo, nh = k->h_hi - k->h_lo;
   if (nh) {
-    if ((rc = g16_msm_sort(ctx, M, d_qs + k->h_lo, G16_SCALARS_MONT, nh, k->H1->c, ctx->sort[1]))) return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, M, ctx->lane[4].acc, ctx->sort[1], k->H1->d_tables, nullptr, slots + PART_H)))
+    if ((rc = g16_msm_sort(ctx, M, d_qs_slice, G16_SCALARS_MONT, nh, k->H1->c, ctx->sort[1]))) return rc;
+    if ((rc = g16_msm_reduce_g1(ctx, M, ctx->lane[4].acc, ctx->sort[1], k->H1->d_tables, nullptr, b.slots + PART_H)))
       return rc;
   }
   if (nw)
     for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->lane[i].done, 0));
-  HIPCHK(ctx, hipMemcpyAsync(out_partials, slots, PART_BYTES,
+  HIPCHK(ctx, hipMemcpyAsync(out_partials, b.slots, PART_BYTES,
                              (flags & G16_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return G16_OK;
+}
+
+static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
+                                   void* out_partials) {
+  const size_t n = size_t(1) << k->log2n;
+  const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
+  ProveBufs b;
+  int32_t rc;
+  if ((rc = prove_bufs(ctx, k, b))) return rc;
+  if ((rc = launch_witness_msms(ctx, k, witness, flags, b))) return rc;
+  // buildABC + quotient (prover.nim:244-260) on the main stream, concurrently with the witness MSMs; replicated on
+  // every rank of a sharded proof unless the caller uses the task-parallel pair g16_prove_partials_begin / _end
+  if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc))) return rc;
+  if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs))) return rc;
+  return launch_h_and_collect(ctx, k, b.d_qs + k->h_lo, flags, b, out_partials);
+}
+
+// ---- sharded proof with a task-parallel quotient ------------------------------------------------------------
+// The reference runs the three coset pipelines of computeSnarkjsScalarCoeffs as three tasks (prover.nim:167-169).
+// Across GPUs each pipeline lives on ONE rank: _begin launches this rank's witness MSMs and computes the pipelines
+// named by task_mask (bit 0: A, bit 1: B, bit 2: C) into d_task_out (n Fr per set bit, ascending); the caller
+// scatters the [h_lo, h_hi) slices of the three coset vectors to their ranks (nim_groth16_amd/distributed.py: three
+// scatters of 32 n / G bytes per destination) while the MSM lanes keep computing; _end forms this rank's H scalars
+// A1*B1 - C1 from the received slices (prover.nim:175-176), runs the H MSM over them and hands out the partials.
+extern "C" int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
+                                            uint32_t task_mask, void* d_task_out) {
+  if (!ctx) return G16_EINVAL;
+  if (!k || !witness || k->device != ctx->device || task_mask > 7 || (task_mask && !d_task_out)) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  if (k->flavour != G16_FLAVOUR_SNARKJS) {
+    ctx->err = "the task-parallel quotient serves snarkjs-flavour keys (JensGroth needs a 7th transform of the whole "
+               "vector: use g16_prove_partials)";
+    return G16_EINVAL;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = size_t(1) << k->log2n;
+  ProveBufs b;
+  int32_t rc = prove_bufs(ctx, k, b);
+  if (!rc) rc = launch_witness_msms(ctx, k, witness, flags, b);
+  if (!rc && task_mask) {
+    rc = build_abc_device(ctx, k, b.d_w, (flags & G16_SCALARS_MONT) ? 1u : 0u, b.d_abc);
+    u256* out = (u256*)d_task_out;
+    for (int v = 0; v < 3 && !rc; ++v)
+      if (task_mask & (1u << v)) {
+        rc = g16_coset_pipeline_device(ctx, b.d_abc + v * n, k->log2n, out);
+        out += n;
+      }
+  }
+  if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // the task outputs are complete; the lanes run on
+    ctx->err = "hipStreamSynchronize failed";
+    rc = G16_EHIP;
+  }
+  if (rc != G16_OK) {
+    ctx_quiesce(ctx);
+    return rc;
+  }
+  ctx->shard_begun = k;
+  return G16_OK;
+}
+
+extern "C" int32_t g16_prove_partials_end(g16_ctx* ctx, const g16_pkey* k, const void* d_a1, const void* d_b1,
+                                          const void* d_c1, uint32_t flags, void* out_partials) {
+  if (!ctx) return G16_EINVAL;
+  const size_t nh = k ? k->h_hi - k->h_lo : 0;
+  if (!k || !out_partials || k->device != ctx->device || (nh && (!d_a1 || !d_b1 || !d_c1))) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  if (ctx->shard_begun != k) {
+    ctx->err = "g16_prove_partials_end without a matching g16_prove_partials_begin on this context";
+    return G16_EINVAL;
+  }
+  ctx->shard_begun = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ProveBufs b;
+  int32_t rc = prove_bufs(ctx, k, b);
+  if (!rc) rc = g16_abc_pointwise_device(ctx, d_a1, d_b1, d_c1, nh, b.d_qs);
+  if (!rc) rc = launch_h_and_collect(ctx, k, b.d_qs, flags, b, out_partials);
+  if (rc != G16_OK) ctx_quiesce(ctx);
+  return rc;
 }
 
 // one workgroup per MSM: res = sum over ranks of that MSM's partial, then canonical affine

@@ -42,9 +42,12 @@ def test_bench_single_gpu_small_domain_contract_line():
 
 
 @pytest.mark.timeout(1000)
-def test_bench_two_ranks_shard_mode_from_a_bare_shell():
-    d = _run("--gpus", "2", "--mode", "shard", "--backend", "gloo", "--log2n", "14", "--steps", "6", "--warmup", "3")
+@pytest.mark.parametrize("quotient", ["tasks", "replicated"])
+def test_bench_two_ranks_shard_mode_from_a_bare_shell(quotient):
+    d = _run("--gpus", "2", "--mode", "shard", "--backend", "gloo", "--log2n", "14", "--steps", "6", "--warmup", "3",
+             "--quotient", quotient)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "shard" and d["value"] > 0
+    assert f"quotient {quotient}" in d["config"]["workload"]
     assert d["cpu_baseline"] is None                       # reported at N = 1 only
 
 

@@ -1,7 +1,8 @@
 """The GPU branch of ShardedProver under a real 2-rank process group on the one-GPU box: both ranks compute their
 g16_prove_partials / g16_prove_combine on device 0 with sharded keys (msm.nim:105-115 ranges), the 768-byte records
 travel through a gloo all-gather, and every rank must end with the proof of the unsharded key, which is in turn
-held to the C oracle.  Domain 2^16: the per-shard window choice and table sizes are the real ones."""
+held to the C oracle.  Both quotient modes: "tasks" (rank 0 runs the A and C coset pipelines, rank 1 the B pipeline,
+three scatters of the slices) and "replicated".  Domain 2^16: the per-shard window choice and table sizes are the real ones."""
 import os
 import socket
 import sys
@@ -22,7 +23,7 @@ def _inputs():
     return r1cs, wit, tox, (rng.fr(), rng.fr())
 
 
-def _rank(rank, world, port, q):
+def _rank(rank, world, port, q, quotient):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import torch.distributed as dist
@@ -35,8 +36,8 @@ def _rank(rank, world, port, q):
     r1cs, wit, tox, (r, s) = _inputs()
     ctx = Context(0)                                   # both ranks share the box's single GPU
     zk = fakeCircuitSetup(r1cs, ToxicWaste(*tox), 1, ctx)
-    sp = ShardedProver(zk, rank, world, ctx=ctx)       # partials_fn=None: the real sharded key on the GPU
-    assert sp.pkey is not None and sp.group_is_cpu()
+    sp = ShardedProver(zk, rank, world, ctx=ctx, quotient=quotient)   # partials_fn=None: the real sharded key on the GPU
+    assert sp.pkey is not None and sp.group_is_cpu() and sp.task_quotient == (quotient == "tasks")
     out = []
     for std in (False, True):
         vals = F.frSeqToStdBytes(wit) if std else F.frSeqToMontBytes(wit)
@@ -50,13 +51,14 @@ def _rank(rank, world, port, q):
 
 
 @pytest.mark.timeout(900)
-def test_sharded_prover_gpu_branch_world2_gloo(ctx, orc):
+@pytest.mark.parametrize("quotient", ["tasks", "replicated"])
+def test_sharded_prover_gpu_branch_world2_gloo(ctx, orc, quotient):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_rank, args=(rk, 2, port, q)) for rk in range(2)]
+    procs = [mpc.Process(target=_rank, args=(rk, 2, port, q, quotient)) for rk in range(2)]
     for p in procs:
         p.start()
     outs = dict(q.get(timeout=800) for _ in range(2))

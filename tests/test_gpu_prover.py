@@ -152,6 +152,62 @@ def test_sharded_proof_single_gpu(ctx, world):
         k.destroy()
 
 
+@pytest.mark.parametrize("world,log2n", [(1, 9), (2, 11), (3, 11), (8, 12), (5, 4)])
+def test_sharded_proof_with_task_parallel_quotient_single_gpu(ctx, orc, world, log2n):
+    """g16_prove_partials_begin / _end on one device, the exchange done by hand: `world` contexts stand for the ranks;
+    rank v mod world computes coset vector v (prover.nim:167-169's three tasks), every rank gets its [h_lo, h_hi)
+    slices, forms A1*B1 - C1 there and runs its share of the H MSM.  The combined proof must equal the unsharded
+    key's, and each coset vector the oracle's shiftEvalDomain (prover.nim:109-113)."""
+    import torch
+    from nim_groth16_amd import Context, loadProvingKey
+    from nim_groth16_amd.distributed import quotientTaskOwner, shardRange
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import squaringChain
+    n = 1 << log2n
+    m = n - 2
+    r1cs, wit = squaringChain(m, seed=9)
+    a, b, g, d, t = _toxic(15)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(a, b, g, d, t), 1, ctx)
+    wb = I.fr_mont_bytes(wit)
+    rng = o.SplitMix64(16)
+    r, s = o.fr_to_mont_bytes(rng.fr()), o.fr_to_mont_bytes(rng.fr())
+    full = loadProvingKey(zk, ctx)
+    want = full.prove(wb, r=r, s=s)
+    ctxs = [Context(0) for _ in range(world)]
+    keys = [loadProvingKey(zk, ctxs[k], shard_index=k, shard_count=world) for k in range(world)]
+    vecs = {}
+    for k in range(world):
+        owned = [v for v in range(3) if quotientTaskOwner(v, world) == k]
+        out = torch.empty(max(1, len(owned)) * n * 32, dtype=torch.uint8, device="cuda")
+        keys[k].prove_partials_begin(wb, sum(1 << v for v in owned), out.data_ptr() if owned else None)
+        for i, v in enumerate(owned):
+            vecs[v] = out[32 * n * i: 32 * n * (i + 1)].clone()
+    torch.cuda.synchronize()
+    # the three coset vectors against the C oracle: quotient_snarkjs = A1*B1 - C1, so check through it
+    Az, Bz, Cz = full.build_abc(wb)
+    qs = orc.quotient_snarkjs(Az, Bz, Cz, log2n)
+    A1, B1, C1 = (I.fr_from_mont(bytes(vecs[v].cpu().numpy())) for v in range(3))
+    assert [(x * y - z) % o.R for x, y, z in zip(A1, B1, C1)] == I.fr_from_mont(qs)
+    if log2n <= 9:
+        assert A1 == o.shift_eval_domain(I.fr_from_mont(Az), o.Domain(n), o.Domain(2 * n).domainGen)
+    recs = b""
+    for k in range(world):
+        lo, hi = shardRange(n, k, world)
+        sl = [vecs[v][32 * lo: 32 * hi].contiguous() for v in range(3)]
+        torch.cuda.synchronize()
+        recs += keys[k].prove_partials_end(*[x.data_ptr() if hi > lo else None for x in sl])
+    assert len(recs) == 768 * world
+    assert keys[0].prove_combine(recs, world, r, s) == want
+    # protocol errors come back as G16_EINVAL, not as a crash
+    from nim_groth16_amd import G16Error
+    with pytest.raises(G16Error):
+        keys[0].prove_partials_end(None, None, None)          # no begin outstanding
+    for k in keys + [full]:
+        k.destroy()
+    for c in ctxs:
+        c.close()
+
+
 def test_files_to_proof_json_end_to_end(ctx, tmp_path):
     """snarkjs-style pipeline (groth16/example/prove.sh:52-59 without circom/snarkjs): .zkey + .wtns files ->
     parse -> GPU prove (raw standard-form witness bytes) -> proof.json / public.json -> verified by the oracle"""
