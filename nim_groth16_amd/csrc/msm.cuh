@@ -624,8 +624,9 @@ __global__ void __launch_bounds__(BLOCK) msm_reduce2(const typename C::Acc* __re
 //   level 3:  y3 = m (s - x3) - w y      zz3 = v zz      zzz3 = w zzz        (x3 = mm - 2s)
 // Lanes 0, 1, 2 of the wave take one product of a level each -- the SAME instruction stream on different operands,
 // so nothing diverges -- and the results travel between levels by ds_bpermute.  One doubling then costs 3 (+1/2)
-// multiplications of wave time instead of 10 1/2.  Every lane holds the same point on entry and on exit; the
-// formulas map the all-zero infinity to itself, so no lane branches.
+// multiplications of wave time instead of 10 1/2.  Every lane must hold the same COORDINATES (not merely the same
+// point: products computed by different lanes are combined) on entry, and does on exit; the formulas map the all-zero
+// infinity to itself, so no lane branches.
 __device__ __forceinline__ u256 wave_get(const u256& v, int src) {
   u256 r;
 #pragma unroll
@@ -693,7 +694,10 @@ __device__ __forceinline__ typename C::Acc wave_allreduce(typename C::Acc v) {
     typename C::Acc other = wave_get_acc<C>(v, lane ^ d);
     C::add(v, other);
   }
-  return v;   // the same total on every lane (group addition is commutative; the result is made canonical later)
+  // Every lane now holds the same POINT but not the same coordinates: a + b and b + a differ in the sign of
+  // (Y, ZZZ).  Callers that go on cooperatively (dbl_coop mixes coordinates across lanes) need one representation:
+  // lane 0's.
+  return wave_get_acc<C>(v, 0);
 }
 template <class C>
 __global__ void __launch_bounds__(128) msm_fold_merged(const typename C::Acc* __restrict__ set_sum,

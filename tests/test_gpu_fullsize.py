@@ -20,7 +20,8 @@ def _bytes(vals):
     return F.frSeqToMontBytes(vals)
 
 
-@pytest.mark.parametrize("group,log2n", [(1, 20), (2, 18), (2, 20)])
+# sizes 2^15 .. 2^19 walk the merged-bucket fold through 2, 4, 8, 16, 32 reduction slices (64 at 2^20)
+@pytest.mark.parametrize("group,log2n", [(1, 20), (2, 18), (2, 20), (1, 15), (1, 16), (1, 17), (1, 19), (2, 15), (2, 16)])
 def test_msm_fullsize_known_discrete_logs(ctx, orc, group, log2n):
     """P_i = k_i * G, so that sum s_i P_i = (sum s_i k_i mod r) * G  (SURVEY 8d config 2 check).  The point set is
     produced by the product's fixed-base kernel (the oracle would take minutes at 2^20); the EXPECTED value is the
