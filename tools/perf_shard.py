@@ -1,28 +1,60 @@
-import sys, time, os
+"""Per-rank cost of ONE sharded 2^20 proof, measured on one GPU by running a single rank's share
+(shard_count = G, shard_index = the most loaded rank):
+  replicated : g16_prove_partials            -- buildABC + all six NTTs on every rank (round 1)
+  tasks      : g16_prove_partials_begin/_end -- the rank's coset pipeline(s) only; the scatter of the slices is NOT
+               included (3 x 32 n / G bytes per rank over xGMI; no multi-GPU box here)
+  tasks, rank without a pipeline (G > 3)."""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
-import torch
-from nim_groth16_amd import Context, loadProvingKey
-from nim_groth16_amd import bn128 as F
-from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
-from nim_groth16_amd.synthetic import SplitMix64, squaringChain
-log2n = 20
+import torch  # noqa: E402
+from nim_groth16_amd import Context, loadProvingKey  # noqa: E402
+from nim_groth16_amd import bn128 as F  # noqa: E402
+from nim_groth16_amd.distributed import quotientTaskOwner, shardRange  # noqa: E402
+from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup  # noqa: E402
+from nim_groth16_amd.synthetic import SplitMix64, squaringChain  # noqa: E402
+
+log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n = 1 << log2n
 ctx = Context(0)
-m = (1 << log2n) - 2
+m = n - 2
 r1cs, wit = squaringChain(m, seed=4)
 rng = SplitMix64(5)
 zkey = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
 wb = F.frSeqToMontBytes(wit)
 d_w = torch.frombuffer(bytearray(wb), dtype=torch.uint8).cuda()
-for G in (1, 2, 4, 8):
-    pk = loadProvingKey(zkey, ctx, shard_index=G - 1, shard_count=G)
-    out = torch.empty(768, dtype=torch.uint8, device="cuda")
+out = torch.empty(768, dtype=torch.uint8, device="cuda")
+task_out = torch.empty(3 * n * 32, dtype=torch.uint8, device="cuda")
+
+
+def timed(fn, reps=10):
     for _ in range(3):
-        pk.prove_partials(d_w.data_ptr(), mont=True, device=True, out=out.data_ptr())
+        fn()
     ctx.synchronize(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(10):
-        pk.prove_partials(d_w.data_ptr(), mont=True, device=True, out=out.data_ptr())
+    for _ in range(reps):
+        fn()
         ctx.synchronize()
-    dt = (time.perf_counter() - t0) / 10
-    print(f"shard_count {G}: one rank's prove_partials {dt*1e3:.2f} ms", flush=True)
-    pk.destroy()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+for G in (1, 2, 4, 8):
+    res = {}
+    for rank in sorted({0, G - 1}):
+        pk = loadProvingKey(zkey, ctx, shard_index=rank, shard_count=G)
+        lo, hi = shardRange(n, rank, G)
+        owned = [v for v in range(3) if quotientTaskOwner(v, G) == rank]
+        mask = sum(1 << v for v in owned)
+        sl = [task_out.data_ptr() + 32 * (n * v + lo) for v in range(3)]     # stand-ins for the received slices
+
+        def tasks():
+            pk.prove_partials_begin(d_w.data_ptr(), mask, task_out.data_ptr() if owned else None, device=True)
+            pk.prove_partials_end(sl[0], sl[1], sl[2], out=out.data_ptr())
+        res[rank] = (timed(lambda: pk.prove_partials(d_w.data_ptr(), mont=True, device=True, out=out.data_ptr())),
+                     timed(tasks), len(owned))
+        pk.destroy()
+    for rank, (rep, tk, nown) in res.items():
+        print(f"shard_count {G} rank {rank}: replicated {rep:.2f} ms | tasks {tk:.2f} ms ({nown} coset pipeline(s) on this rank)",
+              flush=True)

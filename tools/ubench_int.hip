@@ -16,7 +16,7 @@ constexpr int CHAINS = 8;
 constexpr int UNROLL = 4;   // x CHAINS instructions per loop iteration
 
 enum Op { ADD_U32, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24,
-          FMA_F64, ADDC_PAIR, FMA_F32, MAD_U32_U16, LSHL_ADD_U64, MUL_U32_U24, MAD_U64_DEP, LSHR_B64, ALIGNBIT, AND_B32, MAD_U64_SGPR, ADD3_U32, LSHL_OR };
+          FMA_F64, ADDC_PAIR, FMA_F32, MAD_U32_U16, LSHL_ADD_U64, MUL_U32_U24, MAD_U64_DEP, LSHR_B64, ALIGNBIT, AND_B32, MAD_U64_SGPR, ADD3_U32, LSHL_OR, MAD_NOP, MAD_NOP_DEP, MAD_BLOCK8, MAD_BLOCK8_DEP, AND_BLOCK8 };
 
 // Every wave stamps the shader clock (s_memtime: one tick per shader cycle) and the constant 100 MHz counter
 // (s_memrealtime) around its loop; wave 0 of each workgroup stores them.  No clock is assumed anywhere:
@@ -81,6 +81,34 @@ __global__ void __launch_bounds__(256) k(unsigned* out, int iters, unsigned seed
           asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b[i]));
         else if constexpr (OP == MAD_U64_SGPR)
           asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "s"(seed) : "vcc");
+        else if constexpr (OP == MAD_BLOCK8) {  // 8 multiply-adds in ONE asm statement: hipcc pads once per statement
+          if (i == 0)
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %16, %0\n\tv_mad_u64_u32 %1, vcc, %9, %17, %1\n\t"
+                         "v_mad_u64_u32 %2, vcc, %10, %18, %2\n\tv_mad_u64_u32 %3, vcc, %11, %19, %3\n\t"
+                         "v_mad_u64_u32 %4, vcc, %12, %20, %4\n\tv_mad_u64_u32 %5, vcc, %13, %21, %5\n\t"
+                         "v_mad_u64_u32 %6, vcc, %14, %22, %6\n\tv_mad_u64_u32 %7, vcc, %15, %23, %7"
+                         : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])
+                         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+                           "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+        } else if constexpr (OP == MAD_BLOCK8_DEP) {   // the same as ONE dependent chain (a column of a product)
+          if (i == 0)
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\t"
+                         "v_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\t"
+                         "v_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\t"
+                         "v_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0"
+                         : "+v"(w[0])
+                         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+                           "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+        } else if constexpr (OP == AND_BLOCK8) {
+          if (i == 0)
+            asm volatile("v_and_b32 %0, %0, %8\n\tv_and_b32 %1, %1, %8\n\tv_and_b32 %2, %2, %8\n\tv_and_b32 %3, %3, %8\n\t"
+                         "v_and_b32 %4, %4, %8\n\tv_and_b32 %5, %5, %8\n\tv_and_b32 %6, %6, %8\n\tv_and_b32 %7, %7, %8"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                         : "v"(b[0]));
+        } else if constexpr (OP == MAD_NOP)       // what hipcc emits behind every pinned multiply-add: mad + s_nop
+          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\ts_nop 0" : "+v"(w[i]) : "v"(a[i]), "v"(b[i]) : "vcc");
+        else if constexpr (OP == MAD_NOP_DEP)
+          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\ts_nop 0" : "+v"(w[0]) : "v"(a[i]), "v"(b[i]) : "vcc");
         else if constexpr (OP == MAD_U64_DEP)   // single dependent chain through chain 0
           asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[0]) : "v"(a[i]), "v"(b[i]) : "vcc");
       }
@@ -171,6 +199,29 @@ int main() {
     run<ADD3_U32>("v_add3_u32", blocks, iters, out);
     run<LSHL_OR>("v_lshl_or_b32", blocks, iters, out);
     run<MAD_U64_SGPR>("v_mad_u64 sgpr", blocks, iters, out);
+    run<MAD_NOP>("mad + s_nop", blocks, iters, out);          // counted as ONE instruction: the price of the pair
+    run<MAD_NOP_DEP>("mad + s_nop dep", blocks, iters, out);
+    run<MAD_BLOCK8>("mad x8 / asm", blocks, iters, out);       // hipcc pads every asm STATEMENT with one s_nop: the rows
+    run<MAD_BLOCK8_DEP>("mad x8 chain/asm", blocks, iters, out);   // above carry one s_nop per instruction, these 1/8
+    run<AND_BLOCK8>("and x8 / asm", blocks, iters, out);
+  }
+  {   // the accumulate kernels' occupancy: 4 waves per SIMD
+    printf("---- 4 waves/SIMD ----\n");
+    run<MAD_U64_U32>("v_mad_u64_u32", 1024, 8000, out);
+    run<MAD_U64_DEP>("v_mad_u64 dep", 1024, 8000, out);
+    run<MAD_NOP>("mad + s_nop", 1024, 8000, out);
+    run<MAD_NOP_DEP>("mad + s_nop dep", 1024, 8000, out);
+    run<MAD_BLOCK8>("mad x8 / asm", 1024, 8000, out);
+    run<MAD_BLOCK8_DEP>("mad x8 chain/asm", 1024, 8000, out);
+    run<AND_B32>("v_and_b32", 1024, 8000, out);
+    run<AND_BLOCK8>("and x8 / asm", 1024, 8000, out);
+    printf("---- 2 waves/SIMD ----\n");
+    run<MAD_U64_U32>("v_mad_u64_u32", 512, 8000, out);
+    run<MAD_U64_DEP>("v_mad_u64 dep", 512, 8000, out);
+    run<MAD_NOP>("mad + s_nop", 512, 8000, out);
+    run<MAD_NOP_DEP>("mad + s_nop dep", 512, 8000, out);
+    run<MAD_BLOCK8>("mad x8 / asm", 512, 8000, out);
+    run<MAD_BLOCK8_DEP>("mad x8 chain/asm", 512, 8000, out);
   }
   return 0;
 }
