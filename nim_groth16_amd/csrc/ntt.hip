@@ -20,7 +20,9 @@ static int32_t ensure_twiddles(g16_ctx* ctx, uint32_t log2n) {
 // opted in once per process.
 static size_t pass_shmem(uint32_t rho, uint32_t log2b) { return (size_t(32) << (rho + log2b)) + (size_t(16) << rho); }
 static int32_t ntt_kernels_init(g16_ctx* ctx) {
-  static bool done = false;   // benign race: the attribute is idempotent
+  static bool done_on[64] = {};   // per device (the attribute belongs to the device's copy of the code object);
+                                  // benign race: setting it twice is idempotent
+  bool& done = done_on[ctx->device & 63];
   if (done) return G16_OK;
   const int max_shmem = (int)pass_shmem(NTT_MAX_RHO, 2);
   static_assert((size_t(32) * NTT_TILE) + (size_t(16) << NTT_MAX_RHO) <= 160 * 1024, "tile + twiddles must fit the LDS");

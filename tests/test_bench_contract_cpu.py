@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_step14_bench_2p20_final.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_step3_bench_2p20_tails.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -22,11 +22,28 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port")
+    assert "witness from host" in d["config"]["inputs"] and d["keys_resident_per_gpu"] == 1
+
+
+def test_valu_roofline_inputs_are_consistent():
+    """profiles/r02_valu_roofline_inputs.json (tools/valu_roofline.py) -> bench.py's roofline_valu object"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    inp = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_roofline_inputs.json")))
+    k = inp["kernels"]["msm_accum_g1"]
+    assert 0.5 < k["mad_u64_share_of_valu"] < 0.7 and 3.5 < k["mix_issue_cycles_per_inst"] < 4.5
+    assert 4.0 < inp["issue_cycles"]["v_mad_u64_u32"] < 5.0 and 1.8 < k["sustained_clock_ghz"] < 2.5
+    r = bench.valu_roofline("msm_accum_g1", k["duration_us"] / 1e3, None)
+    for key in ("bound", "achieved_ms", "valu_wave_insts_per_launch", "sustained_clock_ghz", "bound_ms_mix", "frac_mix",
+                "bound_ms_multiply_only", "frac_multiply_only"):
+        assert key in r, key
+    assert abs(r["frac_mix"] - k["frac_mix"]) < 0.01 and r["frac_multiply_only"] < r["frac_mix"] < 1.0
 
 
 def test_bench_source_emits_the_same_keys():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for k in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
               '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"',
-              '"frac"', '"cores"', '"kind"', '"sample"'):
+              '"frac"', '"cores"', '"kind"', '"sample"', '"roofline_valu"', '"frac_mix"', '"frac_multiply_only"'):
         assert k in src, k
