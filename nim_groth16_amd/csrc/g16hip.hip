@@ -18,6 +18,8 @@ static G16Env read_env() {
   e.table_window = num("G16_TABLE_WINDOW", 5, 22);
   e.msm_seg = num("G16_MSM_SEG", 8, 4096);
   e.red_slice_log2 = num("G16_RED_SLICE", 8, 11);
+  if (const char* v = getenv("G16_LANES_AFTER_QUOTIENT")) e.lanes_after_quotient = v[0] != '0';
+  if (const char* v = getenv("G16_QUOTIENT_FIRST")) e.quotient_first = v[0] != '0';
   if (const char* v = getenv("G16_MSM_SORT")) e.msm_sort = v[0];
   if (const char* v = getenv("G16_G1_LANES"))
     if (strlen(v) == 3 && strspn(v, "023") == 3)
@@ -81,6 +83,7 @@ int32_t g16_lanes_init(g16_ctx* ctx) {
   }
   if (hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
+  if (hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   return G16_OK;
 }
 
@@ -97,6 +100,7 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
     if (srt.buf.p) (void)hipFree(srt.buf.p);
   if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+  if (ctx->ev_q) (void)hipEventDestroy(ctx->ev_q);
   for (g16_ctx::Buf* b : {&ctx->stage_s, &ctx->stage_p, &ctx->stage_p29, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
                           &ctx->coset[0], &ctx->coset[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
                           &ctx->fb_table[1]})

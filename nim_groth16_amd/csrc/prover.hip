@@ -287,20 +287,27 @@ static int32_t prove_bufs(g16_ctx* ctx, const g16_pkey* k, ProveBufs& b) {
   return G16_OK;
 }
 
-// witness -> HBM, then the four MSMs that consume it (A1, B1, B2, C1: prover.nim:282, 288, 294, 302) on the lane
-// streams.  The witness' signed-digit bucket arrangement is computed once (lane 0) and shared; the four
-// accumulate/reduce pipelines run on four streams so that their latency-bound tails overlap with the other
-// pipelines' accumulation.  Nothing is waited for here.
-static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags,
-                                   const ProveBufs& b) {
-  const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
-  int32_t rc;
+// witness -> HBM (main stream); ev_a marks its arrival
+static int32_t upload_witness(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, const ProveBufs& b) {
   HIPCHK(ctx, hipMemcpyAsync(b.d_w, witness, (size_t)k->nvars * 32,
                              (flags & G16_SCALARS_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                              ctx->stream));
-  hipStream_t M = ctx->stream;
-  HIPCHK(ctx, hipMemsetAsync(b.slots, 0, PART_BYTES, M));   // empty range -> XYZZ infinity (all zero)
-  HIPCHK(ctx, hipEventRecord(ctx->ev_a, M));                // witness resident
+  HIPCHK(ctx, hipMemsetAsync(b.slots, 0, PART_BYTES, ctx->stream));   // empty range -> XYZZ infinity (all zero)
+  HIPCHK(ctx, hipEventRecord(ctx->ev_a, ctx->stream));                // witness resident
+  return G16_OK;
+}
+
+// The four MSMs that consume the witness (A1, B1, B2, C1: prover.nim:282, 288, 294, 302) on the lane streams.  The
+// witness' signed-digit bucket arrangement is computed once (lane 0) and shared; the four accumulate/reduce pipelines
+// run on four streams so that their latency-bound tails overlap with the other pipelines' accumulation.  Nothing is
+// waited for here.  `after` (optional): an event the accumulations wait for in addition to the sort -- the quotient's
+// last kernel: the NTT passes are 1024-thread workgroups that need half a CU's registers at once, and are starved
+// for milliseconds when the (long-running, register-filling) accumulate waves of four lanes get to the CUs first;
+// the sort itself is memory-bound and overlaps the quotient.
+static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, uint32_t flags, const ProveBufs& b,
+                                   hipEvent_t after) {
+  const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
+  int32_t rc;
   const uint32_t wflags = wit_mont ? G16_SCALARS_MONT : 0u;
   const size_t nw = k->w_hi - k->w_lo;
   if (nw) {
@@ -308,7 +315,10 @@ static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const void* 
     HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
     if ((rc = g16_msm_sort(ctx, L[0].stream, b.d_w + k->w_lo, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
-    for (int i = 1; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, ctx->ev_b, 0));
+    for (int i = 0; i < 4; ++i) {
+      if (i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, ctx->ev_b, 0));
+      if (after) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, after, 0));
+    }
     if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, ctx->sort[0], k->B2->d_tables, nullptr, b.slots + PART_B2)))
       return rc;
     // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES (read once per process, g16_env) reassigns them
@@ -326,13 +336,17 @@ static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const void* 
 
 // the H MSM over this key's domain range (prover.nim:301) on the main stream, then join the lanes and hand out the
 // five partials.  d_qs_slice: the H scalars of [h_lo, h_hi), Montgomery.
+static int32_t launch_h_sort(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice) {
+  const size_t nh = k->h_hi - k->h_lo;
+  return nh ? g16_msm_sort(ctx, ctx->stream, d_qs_slice, G16_SCALARS_MONT, nh, k->H1->c, ctx->sort[1]) : G16_OK;
+}
 static int32_t launch_h_and_collect(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice, uint32_t flags,
-                                    const ProveBufs& b, void* out_partials) {
+                                    const ProveBufs& b, void* out_partials, bool sorted = false) {
   int32_t rc;
   hipStream_t M = ctx->stream;
   const size_t nw = k->w_hi - k->w_lo, nh = k->h_hi - k->h_lo;
   if (nh) {
-    if ((rc = g16_msm_sort(ctx, M, d_qs_slice, G16_SCALARS_MONT, nh, k->H1->c, ctx->sort[1]))) return rc;
+    if (!sorted && (rc = launch_h_sort(ctx, k, d_qs_slice))) return rc;
     if ((rc = g16_msm_reduce_g1(ctx, M, ctx->lane[4].acc, ctx->sort[1], k->H1->d_tables, nullptr, b.slots + PART_H)))
       return rc;
   }
@@ -351,12 +365,33 @@ static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* 
   ProveBufs b;
   int32_t rc;
   if ((rc = prove_bufs(ctx, k, b))) return rc;
-  if ((rc = launch_witness_msms(ctx, k, witness, flags, b))) return rc;
-  // buildABC + quotient (prover.nim:244-260) on the main stream, concurrently with the witness MSMs; replicated on
-  // every rank of a sharded proof unless the caller uses the task-parallel pair g16_prove_partials_begin / _end
+  if ((rc = upload_witness(ctx, k, witness, flags, b))) return rc;
+  // Default order: the four witness MSMs are enqueued first, then buildABC + quotient (prover.nim:244-260) and the H
+  // MSM on the main stream, concurrently with them; replicated on every rank of a sharded proof unless the caller
+  // uses the task-parallel pair g16_prove_partials_begin / _end.
+  // The alternative below (G16_QUOTIENT_FIRST=1: the head of the longest dependency chain -- quotient -> sort(qs) -> H
+  // MSM -- goes to the GPU before the ~60 launches of the witness lanes, which optionally wait for it) was measured on
+  // one box against the default (tools/ab_schedule.sh, profiles/r02_ab_schedule.txt): 107.6-108.5 vs 107.9-110.4
+  // proofs/s and 13.1 vs 12.0 ms single-proof latency -- the quotient does finish 6 ms earlier, but the H accumulate
+  // then competes with four lanes instead of running last and alone, and the proof ends no sooner.  Rejected.
+  if (!g16_env().quotient_first) {
+    if ((rc = launch_witness_msms(ctx, k, flags, b, nullptr))) return rc;
+    if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc))) return rc;
+    if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs))) return rc;
+    return launch_h_and_collect(ctx, k, b.d_qs + k->h_lo, flags, b, out_partials);
+  }
   if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc))) return rc;
   if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs))) return rc;
-  return launch_h_and_collect(ctx, k, b.d_qs + k->h_lo, flags, b, out_partials);
+  // ... and the bucket arrangement of the H scalars too: its dozen short kernels would otherwise queue, one after the
+  // other, behind the GPU-filling accumulate waves of the four witness lanes (measured: 6 ms for a 0.5-ms sort)
+  if ((rc = launch_h_sort(ctx, k, b.d_qs + k->h_lo))) return rc;
+  hipEvent_t after = nullptr;
+  if (g16_env().lanes_after_quotient) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_q, ctx->stream));
+    after = ctx->ev_q;
+  }
+  if ((rc = launch_witness_msms(ctx, k, flags, b, after))) return rc;
+  return launch_h_and_collect(ctx, k, b.d_qs + k->h_lo, flags, b, out_partials, true);
 }
 
 // ---- sharded proof with a task-parallel quotient ------------------------------------------------------------
@@ -382,8 +417,8 @@ extern "C" int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* k, con
   const size_t n = size_t(1) << k->log2n;
   ProveBufs b;
   int32_t rc = prove_bufs(ctx, k, b);
-  if (!rc) rc = launch_witness_msms(ctx, k, witness, flags, b);
-  if (!rc && task_mask) {
+  if (!rc) rc = upload_witness(ctx, k, witness, flags, b);
+  if (!rc && task_mask) {   // this rank's coset pipelines go to the GPU first: every other rank waits for their slices
     rc = build_abc_device(ctx, k, b.d_w, (flags & G16_SCALARS_MONT) ? 1u : 0u, b.d_abc);
     u256* out = (u256*)d_task_out;
     for (int v = 0; v < 3 && !rc; ++v)
@@ -392,6 +427,12 @@ extern "C" int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* k, con
         out += n;
       }
   }
+  hipEvent_t after = nullptr;
+  if (!rc && task_mask && g16_env().quotient_first && g16_env().lanes_after_quotient) {
+    if (hipEventRecord(ctx->ev_q, ctx->stream) != hipSuccess) rc = G16_EHIP;
+    after = ctx->ev_q;
+  }
+  if (!rc) rc = launch_witness_msms(ctx, k, flags, b, after);
   if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // the task outputs are complete; the lanes run on
     ctx->err = "hipStreamSynchronize failed";
     rc = G16_EHIP;
