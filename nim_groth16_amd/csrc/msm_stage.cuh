@@ -24,6 +24,12 @@ static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort&
   const MsmParams& P = S.P;
   const bool g2 = sizeof(typename C::Aff) == 128;
   auto* partial = (typename Ec29<C>::Acc*)partial_;
+  // Grid sizes: both kernels loop grid-stride over the list of split buckets (all but empty for uniform or circom-like
+  // scalars).  In the timeline of a proof these launches look expensive (3-4 ms, against 0.05 ms alone) because their
+  // workgroups queue behind the accumulate waves of the other lanes; shrinking the grids to 128 / 32 workgroups was
+  // measured (tools/ab_heavy_grid.sh, profiles/r02_ab_heavy_grid.txt): no change in proofs/s or latency -- the in-order
+  // reduce behind them waits for the same slots -- and 30 % slower MSMs for scalars with thousands of split buckets
+  // (tools/perf_skew.py "256 values": 3.92 -> 5.11 ms).  Kept at 1024 / 256.
   KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, heavy_block<C>(),
              heavy_block<C>() * sizeof(typename Ec29<C>::Acc), S.heavy, S.info, S.offset, S.xoff, P, partial);
   KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy_small<C>, 256, MSM_BLOCK, 0, S.heavy, S.info,

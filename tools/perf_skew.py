@@ -20,8 +20,11 @@ def main():
     pts = ctx.fixed_base(1, F.frSeqToMontBytes(ks))
     h = ctx.register_points(1, pts, n)
     big = _fr_stream(9, 16)
+    v256, v4096 = _fr_stream(10, 256), _fr_stream(11, 4096)
     cases = {"all equal": [big[0]] * n, "2 values": [big[i & 1] for i in range(n)],
              "16 values": [big[i & 15] for i in range(n)], "all < 2^8": [(i * 7 + 1) & 255 for i in range(n)],
+             "256 values": [v256[i & 255] for i in range(n)],      # 3328 buckets of 4096 entries each
+             "4096 values": [v4096[i & 4095] for i in range(n)],   # 53 k buckets of 256 entries each
              "uniform": _fr_stream(2, n)}
     for name, sc in cases.items():
         sb = F.frSeqToMontBytes(sc)
