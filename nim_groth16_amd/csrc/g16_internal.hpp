@@ -23,6 +23,7 @@ struct G16Env {
   int g1_lanes[3] = {0, 2, 3};   // G16_G1_LANES  lanes of the A1 / B1 / C1 MSMs (three digits from {0,2,3})
   char stream_prio[7] = "lhllln";   // G16_STREAM_PRIO  six characters from {h, n, l}
   int red_slice_log2 = 0;  // G16_RED_SLICE    log2 of the chunks per reduce2 slice of a merged bucket set (8..11)
+  int ntt_tile = 2048;            // G16_NTT_TILE = 1024 | 2048 | 4096: NTT workgroup geometry (ntt.cuh)
   // launch order of a proof (experiments; the defaults are the measured optimum, tools/ab_schedule.sh):
   int quotient_first = 0;         // G16_QUOTIENT_FIRST=1: enqueue buildABC + quotient + sort(qs) before the witness MSMs
   int lanes_after_quotient = 0;   // G16_LANES_AFTER_QUOTIENT=1 (with the above): the witness accumulations wait for them

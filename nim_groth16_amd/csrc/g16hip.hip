@@ -20,6 +20,7 @@ static G16Env read_env() {
   e.red_slice_log2 = num("G16_RED_SLICE", 8, 11);
   if (const char* v = getenv("G16_LANES_AFTER_QUOTIENT")) e.lanes_after_quotient = v[0] != '0';
   if (const char* v = getenv("G16_QUOTIENT_FIRST")) e.quotient_first = v[0] != '0';
+  if (const char* v = getenv("G16_NTT_TILE")) e.ntt_tile = atoi(v) == 1024 ? 1024 : atoi(v) == 4096 ? 4096 : 2048;
   if (const char* v = getenv("G16_MSM_SORT")) e.msm_sort = v[0];
   if (const char* v = getenv("G16_G1_LANES"))
     if (strlen(v) == 3 && strspn(v, "023") == 3)

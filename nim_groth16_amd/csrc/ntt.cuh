@@ -59,13 +59,26 @@ __device__ __forceinline__ u256 ntt_tw(const u256* __restrict__ tw, uint32_t e, 
   return Fr::neg(tw[e - half]);
 }
 
-// Workgroup geometry.  A workgroup of NTT_BLOCK threads owns a tile of up to NTT_TILE elements = B bases x R points
-// (R = 2^rho <= 1024): 128 KB of the CU's 160 KB LDS + 16 KB of inner twiddles, one workgroup per CU, 4 waves per
-// SIMD.  With rho up to 10 a 2^20 transform is TWO passes (10 + 10 stages; 2^21..2^30: three), and a tile still
-// covers B >= 4 consecutive bases, i.e. whole 128-byte lines on every global access.
+// Workgroup geometry.  A workgroup owns a tile of B bases x R points (R = 2^rho), B * R = TILE elements in LDS plus
+// R/2 inner twiddles.  Three geometries are instantiated; G16_NTT_TILE (read once per process) selects one:
+//   2048 (default)  512 threads, 64 KB tiles, rho <= 10: a 2^20 transform is TWO passes (10 + 10 stages; 2^21..2^30:
+//                   three) and two workgroups fit a CU, so one's load phase overlaps the other's butterflies;
+//                   B = 2 at rho = 10: 64-byte segments, neighbouring tiles on the same XCD (ntt_tile_of_block)
+//   4096            1024 threads, 128 KB tiles, rho <= 10, B >= 4 (whole 128-byte lines), one workgroup per CU
+//   1024            256 threads, 32 KB tiles, rho <= 8: three passes at 2^20 (round 1's geometry)
+// Same box, 2^20 (tools/ab_ntt_tile.sh, profiles/r02_ab_ntt_tile.txt): quotient 0.851 / 0.818 / 0.811 ms and
+// 107.6 / 108.7 / 110.4 proofs/s for 4096 / 2048 / 1024.  The passes are VALU-bound, so the extra pass of the small
+// tiles costs HBM bytes (1.14 GB per quotient instead of 0.74 GB), not time, and their small workgroups slot in more
+// easily beside the register-filling accumulate waves of the other streams (+1.5 % proofs/s); the default keeps the
+// two-pass traffic and has the lowest single-proof latency.
 constexpr int NTT_BLOCK = 1024;
 constexpr int NTT_TILE = 4096;
 constexpr uint32_t NTT_MAX_RHO = 10;
+constexpr int NTT_BLOCK_SMALL = 256;
+constexpr int NTT_TILE_SMALL = 1024;
+constexpr uint32_t NTT_MAX_RHO_SMALL = 8;
+constexpr int NTT_BLOCK_MID = 512;
+constexpr int NTT_TILE_MID = 2048;
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? __brev(x) >> (32 - bits) : 0u; }
 
@@ -160,14 +173,14 @@ static __global__ void __launch_bounds__(BLOCK) ntt_pass(const u256* __restrict_
 //   acc = A1 ;  acc *= B1 ;  acc -= C1          ( ys[j] = A1[j]*B1[j] - C1[j], prover.nim:175-176 )
 // in registers ( * invZ1 = -1/2 for the JensGroth flavour, prover.nim:127-128,141 ), so the three transformed
 // vectors are never written to HBM: out receives n elements instead of 3n written + 3n read + n written.
-template <int BLOCK>
+template <int BLOCK, int TILE>
 static __global__ void __launch_bounds__(BLOCK) ntt_last_pass_abc(const u256* __restrict__ x, u256* __restrict__ out,
                                                                const u256* __restrict__ tw, uint32_t log2n,
                                                                uint32_t log2s, uint32_t rho, uint32_t log2b,
                                                                size_t xstride, int mul_invz) {
   extern __shared__ __align__(16) unsigned char smem[];
   u256* lds = reinterpret_cast<u256*>(smem);
-  constexpr int PER = NTT_TILE / BLOCK;   // output elements per thread (the tile may be smaller: guarded)
+  constexpr int PER = TILE / BLOCK;   // output elements per thread (the tile may be smaller: guarded)
   const uint32_t R = 1u << rho, B = 1u << log2b;
   const uint32_t nR = 1u << (log2n - rho);
   const uint32_t base0 = ntt_tile_of_block(blockIdx.x, gridDim.x) << log2b;

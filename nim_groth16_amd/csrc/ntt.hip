@@ -28,7 +28,11 @@ static int32_t ntt_kernels_init(g16_ctx* ctx) {
   static_assert((size_t(32) * NTT_TILE) + (size_t(16) << NTT_MAX_RHO) <= 160 * 1024, "tile + twiddles must fit the LDS");
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass<NTT_BLOCK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
-  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_last_pass_abc<NTT_BLOCK>),
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_last_pass_abc<NTT_BLOCK, NTT_TILE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass<NTT_BLOCK_MID>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_last_pass_abc<NTT_BLOCK_MID, NTT_TILE_MID>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
   done = true;
   return G16_OK;
@@ -50,8 +54,10 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
       HIPCHK(ctx, hipMemcpyAsync(out + b * out_stride, in + b * in_stride, 32, hipMemcpyDeviceToDevice, ctx->stream));
     return G16_OK;  // n = 1: 1/n = 1 and eta^0 = 1
   }
-  // passes of <= 10 stages: one up to 2^10, two up to 2^20, three beyond
-  const uint32_t npass = log2n ? (log2n + NTT_MAX_RHO - 1) / NTT_MAX_RHO : 1;
+  // passes of <= 10 stages: one up to 2^10, two up to 2^20, three beyond (small geometry: <= 8 stages per pass)
+  const bool small = g16_env().ntt_tile == NTT_TILE_SMALL, mid = g16_env().ntt_tile == NTT_TILE_MID;
+  const uint32_t max_rho = small ? NTT_MAX_RHO_SMALL : NTT_MAX_RHO, log2tile = small ? 10 : mid ? 11 : 12;
+  const uint32_t npass = log2n ? (log2n + max_rho - 1) / max_rho : 1;
   u256 *tmpA = nullptr, *tmpB = nullptr;
   if (npass > 1) {
     if ((rc = ensure(ctx, ctx->ntt_tmp, (npass > 2 ? 2 : 1) * n * 32 * batch))) return rc;
@@ -63,21 +69,37 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
   uint32_t log2s = 0;
   for (uint32_t p = 0; p < npass; ++p) {
     uint32_t rho = log2n / npass + (p < log2n % npass ? 1u : 0u);
-    uint32_t log2b = 12 - rho;   // NTT_TILE = 2^12 elements
+    uint32_t log2b = log2tile - rho;
     if (log2b > log2n - rho) log2b = log2n - rho;
     const bool last = p + 1 == npass;
     const size_t shmem = pass_shmem(rho, log2b);
     const uint32_t ntiles = 1u << (log2n - rho - log2b);
     if (last && fuse_abc) {
-      KLAUNCH(ctx, "ntt_last_pass_abc", ntt_last_pass_abc<NTT_BLOCK>, ntiles, NTT_BLOCK, shmem, src, out,
-              (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, src_stride, fuse_abc == 2 ? 1 : 0);
+      if (small)
+        KLAUNCH(ctx, "ntt_last_pass_abc", (ntt_last_pass_abc<NTT_BLOCK_SMALL, NTT_TILE_SMALL>), ntiles, NTT_BLOCK_SMALL,
+                shmem, src, out, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, src_stride, fuse_abc == 2 ? 1 : 0);
+      else if (mid)
+        KLAUNCH(ctx, "ntt_last_pass_abc", (ntt_last_pass_abc<NTT_BLOCK_MID, NTT_TILE_MID>), ntiles, NTT_BLOCK_MID,
+                shmem, src, out, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, src_stride, fuse_abc == 2 ? 1 : 0);
+      else
+        KLAUNCH(ctx, "ntt_last_pass_abc", (ntt_last_pass_abc<NTT_BLOCK, NTT_TILE>), ntiles, NTT_BLOCK, shmem, src, out,
+                (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, src_stride, fuse_abc == 2 ? 1 : 0);
       break;
     }
     u256* dst = last ? out : ((p & 1) ? tmpB : tmpA);
     const size_t dst_stride = last ? out_stride : n;
-    KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK>, dim3(ntiles, batch), NTT_BLOCK, shmem,
-            src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse, last ? 1 : 0, src_stride, dst_stride,
-            last ? scale : (const u256*)nullptr);
+    if (small)
+      KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK_SMALL>, dim3(ntiles, batch),
+              NTT_BLOCK_SMALL, shmem, src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse,
+              last ? 1 : 0, src_stride, dst_stride, last ? scale : (const u256*)nullptr);
+    else if (mid)
+      KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK_MID>, dim3(ntiles, batch),
+              NTT_BLOCK_MID, shmem, src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse,
+              last ? 1 : 0, src_stride, dst_stride, last ? scale : (const u256*)nullptr);
+    else
+      KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK>, dim3(ntiles, batch), NTT_BLOCK, shmem,
+              src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse, last ? 1 : 0, src_stride,
+              dst_stride, last ? scale : (const u256*)nullptr);
     src = dst;
     src_stride = dst_stride;
     log2s += rho;
@@ -87,7 +109,8 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
 }
 
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse) {
-  if (d_src == d_dst && log2n <= NTT_MAX_RHO && log2n > 0) {   // single pass: never in place
+  const uint32_t one_pass = g16_env().ntt_tile == NTT_TILE_SMALL ? NTT_MAX_RHO_SMALL : NTT_MAX_RHO;
+  if (d_src == d_dst && log2n <= one_pass && log2n > 0) {   // single pass: never in place
     int32_t rc = ensure(ctx, ctx->ntt_tmp, (size_t(32) << log2n));
     if (rc) return rc;
     if ((rc = ntt_batched(ctx, (const u256*)d_src, 0, (u256*)ctx->ntt_tmp.p, 0, 1, log2n, inverse, nullptr))) return rc;
@@ -131,7 +154,7 @@ int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, cons
     HIPCHK(ctx, hipMemcpyAsync(X + n, d_b, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(X + 2 * n, d_c, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
     in = X;
-    if (log2n <= NTT_MAX_RHO) {   // a single pass cannot run in place: stage behind the work area
+    if (log2n <= (g16_env().ntt_tile == NTT_TILE_SMALL ? NTT_MAX_RHO_SMALL : NTT_MAX_RHO)) {   // a single pass cannot run in place: stage behind the work area
       if ((rc = ensure(ctx, ctx->ntt_tmp, 3 * n * 32))) return rc;
       HIPCHK(ctx, hipMemcpyAsync(ctx->ntt_tmp.p, X, 3 * n * 32, hipMemcpyDeviceToDevice, ctx->stream));
       in = (const u256*)ctx->ntt_tmp.p;
