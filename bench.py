@@ -182,11 +182,13 @@ def main(argv=None):
     proofs = [None] * NWITNESS         # last proof seen per witness
     plock = threading.Lock()
 
+    errors = []                        # worker threads cannot end the process: failures are collected and re-raised
+
     def keep(i, p):
         with plock:
             k = i % NWITNESS
             if proofs[k] is not None and proofs[k] != p:
-                raise SystemExit("FAIL: two proofs of the same witness differ")
+                errors.append(f"two proofs of witness {k} differ (step {i})")
             proofs[k] = p
 
     def run(count, hbm=False):
@@ -194,16 +196,24 @@ def main(argv=None):
         if inflight == 1:
             for i in range(count):
                 keep(i, step(i, 0, hbm))
+            if errors:
+                raise SystemExit("FAIL: " + "; ".join(errors))
             return
 
         def work(j):
-            for i in range(j, count, inflight):
-                keep(i, step(i, j, hbm))
+            try:
+                for i in range(j, count, inflight):
+                    keep(i, step(i, j, hbm))
+            except BaseException as e:      # a G16Error in a worker must fail the run, not just end the thread
+                with plock:
+                    errors.append(f"worker {j}: {e!r}")
         th = [threading.Thread(target=work, args=(j,)) for j in range(inflight)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        if errors:
+            raise SystemExit("FAIL: " + "; ".join(errors))
 
     run(max(args.warmup, inflight, NWITNESS), hbm=args.witness == "hbm")
     barrier()
