@@ -16,7 +16,9 @@ from nim_groth16_amd.distributed import quotientTaskOwner, shardRange  # noqa: E
 from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup  # noqa: E402
 from nim_groth16_amd.synthetic import SplitMix64, squaringChain  # noqa: E402
 
-log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+log2n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
+CHECK = "--check" in sys.argv      # also prove shard by shard (all G ranks in turn, task-parallel quotient with the
+                                   # exchange done by hand) and require the combined proof == the unsharded key's
 n = 1 << log2n
 ctx = Context(0)
 m = n - 2
@@ -40,8 +42,37 @@ def timed(fn, reps=10):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+rb, sb = F.frToMontBytes(rng.fr()), F.frToMontBytes(rng.fr())
+want = None
 for G in (1, 2, 4, 8):
     res = {}
+    if CHECK:
+        vecs, recs = {}, b""
+        keys = []
+        for rank in range(G):
+            pk = loadProvingKey(zkey, ctx, shard_index=rank, shard_count=G)
+            owned = [v for v in range(3) if quotientTaskOwner(v, G) == rank]
+            tmp = torch.empty(max(1, len(owned)) * n * 32, dtype=torch.uint8, device="cuda")
+            pk.prove_partials_begin(d_w.data_ptr(), sum(1 << v for v in owned), tmp.data_ptr() if owned else None, device=True)
+            for i, v in enumerate(owned):
+                vecs[v] = tmp[32 * n * i: 32 * n * (i + 1)].clone()
+            # one context stands for every rank here, so each rank's proof is finished before the next begins;
+            # ranks that need a vector computed by a LATER rank (only G = 2: rank 0 needs B from rank 1) are
+            # completed in a second sweep
+            keys.append(pk)
+            if all(v in vecs for v in range(3)):
+                lo, hi = shardRange(n, rank, G)
+                torch.cuda.synchronize()
+                recs += pk.prove_partials_end(*[vecs[v][32 * lo: 32 * hi].contiguous().data_ptr() for v in range(3)])
+            else:
+                recs += pk.prove_partials(d_w.data_ptr(), mont=True, device=True)   # replicated quotient: same record
+        proof = keys[0].prove_combine(recs, G, rb, sb)
+        for pk in keys:
+            pk.destroy()
+        if want is None:
+            want = proof
+        assert proof == want, f"sharded proof differs at G = {G}"
+        print(f"shard_count {G}: the proof combined from {G} shard records equals the unsharded proof", flush=True)
     for rank in sorted({0, G - 1}):
         pk = loadProvingKey(zkey, ctx, shard_index=rank, shard_count=G)
         lo, hi = shardRange(n, rank, G)
