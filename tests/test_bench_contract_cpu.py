@@ -47,3 +47,24 @@ def test_bench_source_emits_the_same_keys():
               '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"',
               '"frac"', '"cores"', '"kind"', '"sample"', '"roofline_valu"', '"frac_mix"', '"frac_multiply_only"'):
         assert k in src, k
+
+
+def test_accumulate_hot_loops_keep_their_instruction_budget():
+    """Static regression guard on the built objects (tools/valu_roofline.py: llvm-objdump of the gfx950 code object):
+    one mixed addition of msm_accum<G1> is 6 mul + 2 sqr + one 2-term dot product in the 9x29 field = 1467
+    v_mad_u64_u32 (6*162 + 2*126 + 243), and the whole loop body stays within the budget the roofline accounting
+     is written for.  Skipped when the library has not been built."""
+    import sys
+    import pytest
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_roofline as V
+    csrc = os.path.join(ROOT, "nim_groth16_amd", "csrc")
+    if not os.path.exists(os.path.join(csrc, "msm_g1_accum.o")) or not os.path.exists(os.path.join(V.LLVM, "llvm-objdump")):
+        pytest.skip("objects or llvm-objdump not present")
+    g1 = V.hot_loop_mix(V.code_object(os.path.join(csrc, "msm_g1_accum.o")), r"msm_accum")
+    valu = sum(c for op, c in g1.items() if op.startswith("v_"))
+    assert g1["v_mad_u64_u32"] == 6 * 162 + 2 * 126 + 243 == 1467
+    assert valu <= 2500, valu                                # 2422 when this was written
+    assert not any(op.startswith("scratch_store") for op in g1), "the G1 accumulate loop spills"
+    g2 = V.hot_loop_mix(V.code_object(os.path.join(csrc, "msm_g2_accum.o")), r"msm_accum")
+    assert 4300 <= g2["v_mad_u64_u32"] <= 4400 and sum(c for op, c in g2.items() if op.startswith("v_")) <= 6700
