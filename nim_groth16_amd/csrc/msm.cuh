@@ -21,6 +21,10 @@
 namespace g16 {
 
 constexpr int MSM_BLOCK = 256;
+#ifndef G16_ACC_BLOCK
+#define G16_ACC_BLOCK 256
+#endif
+constexpr int ACC_BLOCK = G16_ACC_BLOCK;   // workgroup size of the accumulate kernels (no LDS, no barriers: dispatch granularity only)
 #ifndef G16_G2_WAVES
 #define G16_G2_WAVES 2
 #endif
@@ -432,14 +436,14 @@ static __global__ void __launch_bounds__(PERM_BLOCK) perm_scatter(const uint32_t
 // occupancy target: G1 fits 4 waves/SIMD (<=128 VGPRs); G2 is bounded to 256 registers (2 waves/SIMD;
 // 3 waves/SIMD with spills measured slower: 3.88 ms vs 3.52 ms on the 8x32 kernel)
 template <class C>
-__global__ void __launch_bounds__(MSM_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : G16_G2_WAVES)
+__global__ void __launch_bounds__(ACC_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : G16_G2_WAVES)
 msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __restrict__ entries,
           const uint32_t* __restrict__ offset, const uint2* __restrict__ xseg, const uint32_t* __restrict__ info,
           const uint32_t* __restrict__ perm, MsmParams P, typename Ec29<C>::Acc* __restrict__ partial) {
   using E = Ec29<C>;
   // task order = dispatch order: the extra segments of split buckets (the longest tasks, L entries each)
   // first, then the buckets by descending size, so that no long task is left for the tail of the launch
-  const uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
+  const uint32_t t = blockIdx.x * ACC_BLOCK + threadIdx.x;
   const uint32_t nx = info[1] < P.max_extra ? info[1] : P.max_extra;
   uint32_t b, s, slot;
   if (t < nx) {

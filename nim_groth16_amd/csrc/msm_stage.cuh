@@ -12,8 +12,8 @@ static int32_t stage_accum(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort&
   const MsmParams& P = S.P;
   const bool g2 = sizeof(typename C::Aff) == 128;
   const uint32_t ntask = P.nbuckets + P.max_extra;
-  KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + MSM_BLOCK - 1) / MSM_BLOCK,
-             MSM_BLOCK, 0, (const typename Ec29<C>::Tab*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
+  KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + ACC_BLOCK - 1) / ACC_BLOCK,
+             ACC_BLOCK, 0, (const typename Ec29<C>::Tab*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
              (typename Ec29<C>::Acc*)partial);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
@@ -27,7 +27,7 @@ static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort&
   // Grid sizes: both kernels loop grid-stride over the list of split buckets (all but empty for uniform or circom-like
   // scalars).  In the timeline of a proof these launches look expensive (3-4 ms, against 0.05 ms alone) because their
   // workgroups queue behind the accumulate waves of the other lanes; shrinking the grids to 128 / 32 workgroups was
-  // measured (tools/ab_heavy_grid.sh, profiles/r02_ab_heavy_grid.txt): no change in proofs/s or latency -- the in-order
+  // measured (tools/ab_builds.sh, profiles/r02_ab_heavy_grid.txt): no change in proofs/s or latency -- the in-order
   // reduce behind them waits for the same slots -- and 30 % slower MSMs for scalars with thousands of split buckets
   // (tools/perf_skew.py "256 values": 3.92 -> 5.11 ms).  Kept at 1024 / 256.
   KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, heavy_block<C>(),

@@ -1,5 +1,5 @@
 # same-box A/B of two builds of libg16hip.so (G16HIP_LIB selects the library): skew cases, then the bench twice each
-#   bash tools/ab_heavy_grid.sh build_variants/libA.so build_variants/libB.so
+#   bash tools/ab_builds.sh build_variants/libA.so build_variants/libB.so
 for lib in "$@"; do echo "== $lib"; G16HIP_LIB=$PWD/$lib python tools/perf_skew.py 2>&1 | grep -v amdgpu.ids; done
 for rep in 1 2; do
 for lib in "$@"; do
