@@ -505,6 +505,22 @@ __global__ void selftest_kernel(uint32_t* out) {
   // inverse
   ok &= Fp::eq(Fp::mul(three, Fp::inv(three)), one);
   out[0] = ok;
+  // inputs / expected values of the host-driven known-answer checks below (out + 16 words onwards):
+  //   points {G, 2G, G}, scalars {1, 2, 3} (standard form)  ->  MSM = 8G ;  NTT input e_0 -> all ones
+  g1_aff* pts = reinterpret_cast<g1_aff*>(out + 16);
+  g1_aff g2x = G1::to_affine(G1::dbl(G1::from_affine(g)));
+  pts[0] = g;
+  pts[1] = g2x;
+  pts[2] = g;
+  pts[3] = G1::to_affine(G1::dbl(G1::dbl(G1::dbl(G1::from_affine(g)))));   // 8G: the expected MSM value
+  u256* sc = reinterpret_cast<u256*>(out + 16 + 64);
+  for (int i = 0; i < 3; ++i) {
+    sc[i] = Fr::zero();
+    sc[i].v[0] = (uint32_t)i + 1;
+  }
+  u256* nt = reinterpret_cast<u256*>(out + 16 + 64 + 24);   // 8 Fr: e_0 in Montgomery form
+  for (int i = 0; i < 8; ++i) nt[i] = i == 0 ? Fr::one() : Fr::zero();
+  nt[8] = Fr::one();                                          // what every output element must equal
 }
 
 extern "C" int32_t g16_selftest(g16_ctx* ctx) {
@@ -512,14 +528,39 @@ extern "C" int32_t g16_selftest(g16_ctx* ctx) {
   static_assert(sizeof(u256) == 32 && sizeof(g1_aff) == 64 && sizeof(g2_aff) == 128, "layout");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int32_t rc;
-  if ((rc = ensure(ctx, ctx->stage_o, 512))) return rc;
-  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, (uint32_t*)ctx->stage_o.p);
+  g16_ctx::Buf st;   // own scratch: the MSM / NTT below use the context's staging buffers
+  if ((rc = ensure(ctx, st, 4096))) return rc;
+  uint32_t* d = (uint32_t*)st.p;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
   uint32_t ok = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&ok, ctx->stage_o.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (ok != 1) {
-    ctx->err = "device arithmetic self-test failed";
-    return G16_ESELFTEST;
-  }
-  return G16_OK;
+  struct {
+    g1_aff msm, want;
+    u256 ntt[8], one;
+  } h;
+  auto finish = [&](int32_t code, const char* msg) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(st.p);
+    if (code) ctx->err = msg;
+    return code;
+  };
+  // known-answer MSM through the whole Pippenger pipeline (1*G + 2*(2G) + 3*G = 8G) and NTT (e_0 -> all ones)
+  const g1_aff* d_pts = reinterpret_cast<const g1_aff*>(d + 16);
+  const u256* d_sc = reinterpret_cast<const u256*>(d + 16 + 64);
+  u256* d_nt = reinterpret_cast<u256*>(d + 16 + 64 + 24);
+  g1_aff* d_res = reinterpret_cast<g1_aff*>(d + 16 + 64 + 24 + 72);
+  u256* d_nout = reinterpret_cast<u256*>(d + 16 + 64 + 24 + 72 + 16);
+  if ((rc = g16_msm_device_g1(ctx, d_sc, G16_SCALARS_STD, d_pts, 3, d_res, nullptr, 0))) return finish(rc, "self-test MSM failed to launch");
+  if ((rc = g16_ntt_device(ctx, d_nt, d_nout, 3, 0))) return finish(rc, "self-test NTT failed to launch");
+  if (hipMemcpyAsync(&ok, d, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(&h.msm, d_res, 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(&h.want, d_pts + 3, 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(h.ntt, d_nout, 256, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(&h.one, d_nt + 8, 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return finish(G16_EHIP, "self-test copy failed");
+  if (ok != 1) return finish(G16_ESELFTEST, "device arithmetic self-test failed");
+  if (memcmp(&h.msm, &h.want, 64) != 0) return finish(G16_ESELFTEST, "known-answer MSM self-test failed");
+  for (int i = 0; i < 8; ++i)
+    if (memcmp(&h.ntt[i], &h.one, 32) != 0) return finish(G16_ESELFTEST, "known-answer NTT self-test failed");
+  return finish(G16_OK, "");
 }
