@@ -301,9 +301,9 @@ static int32_t upload_witness(g16_ctx* ctx, const g16_pkey* k, const void* witne
 // witness' signed-digit bucket arrangement is computed once (lane 0) and shared; the four accumulate/reduce pipelines
 // run on four streams so that their latency-bound tails overlap with the other pipelines' accumulation.  Nothing is
 // waited for here.  `after` (optional): an event the accumulations wait for in addition to the sort -- the quotient's
-// last kernel: the NTT passes are 1024-thread workgroups that need half a CU's registers at once, and are starved
-// for milliseconds when the (long-running, register-filling) accumulate waves of four lanes get to the CUs first;
-// the sort itself is memory-bound and overlaps the quotient.
+// last kernel (G16_QUOTIENT_FIRST / G16_LANES_AFTER_QUOTIENT experiments): the NTT passes are large workgroups (512
+// threads + 80 KB of LDS) that are starved for milliseconds when the long-running, register-filling accumulate waves
+// of four lanes get to the CUs first; the sort itself is memory-bound and overlaps the quotient.
 static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, uint32_t flags, const ProveBufs& b,
                                    hipEvent_t after) {
   const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
