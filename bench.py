@@ -202,6 +202,7 @@ def main(argv=None):
 
         def work(j):
             try:
+                torch.cuda.set_device(local)     # a new host thread starts on device 0 (the library sets it per call too)
                 for i in range(j, count, inflight):
                     keep(i, step(i, j, hbm))
             except BaseException as e:      # a G16Error in a worker must fail the run, not just end the thread

@@ -17,7 +17,8 @@
  *
  * Error convention: every function returns 0 on success or a negative G16_E* code; nothing
  * throws or aborts across the boundary (the reference uses `assert`, msm.nim:97, ntt.nim:56-57).
- * A g16_ctx is used by one host thread at a time; distinct contexts are independent.
+ * A g16_ctx is used by one host thread at a time (any thread: every call makes the context's device the calling
+ * thread's current HIP device); distinct contexts are independent.
  * Registered point sets, proving keys and verification keys (g16_points / g16_pkey / g16_vkey) are immutable and
  * belong to the DEVICE of the context that created them: any context of that device may use them, concurrently
  * (the in-flight proofs of one GPU share one resident key), and they may be released before or after any context.
@@ -51,6 +52,7 @@ typedef struct g16_points g16_points; /* device-resident point set (ProverPoints
 #define G16_SCALARS_DEVICE 2u /* g16_msm_points only: the scalar pointer is a device (HBM) pointer       */
 #define G16_OUT_PARTIAL 4u    /* g16_msm_points only: write the 128/256-byte XYZZ partial, not the affine */
 #define G16_OUT_DEVICE 8u     /* g16_prove_partials only: the output pointer is a device pointer           */
+#define G16_NO_HOST_SYNC 32u  /* g16_prove_partials_begin/_end: do not block the host (see there)             */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int32_t g16_ctx_create(int32_t device, g16_ctx** out);
@@ -198,7 +200,14 @@ int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* key, const void* partial
  *      from the ranks that own them -- three scatters; 32 * domainSize / count bytes per slice)
  *  g16_prove_partials_end: forms this rank's H scalars A1*B1 - C1 from the received slices (device pointers,
  *      h_hi - h_lo Fr each; prover.nim:175-176), runs the H MSM over them, joins the witness MSMs and writes the
- *      768-byte record exactly like g16_prove_partials.  Then g16_prove_combine as usual. */
+ *      768-byte record exactly like g16_prove_partials.  Then g16_prove_combine as usual.
+ *  Between _begin and _end the witness MSMs are in flight on this context's workspaces.  Only g16_ctx_synchronize
+ *  and the g16_profile_* calls leave them alone; ANY other call on the context first waits for them and cancels
+ *  the pending proof (a later _end returns G16_EINVAL) -- so a caller whose exchange failed may simply go on, and
+ *  one that wants to overlap two sharded proofs uses two contexts (nim_groth16_amd/distributed.py does).
+ *  flags for _begin additionally: G16_NO_HOST_SYNC -- return without waiting for the coset vectors; the caller
+ *  orders its exchange behind them through the context's stream (g16_ctx_set_stream: e.g. torch's current stream,
+ *  on which the collective is then enqueued). */
 int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags,
                                  uint32_t task_mask, void* d_task_out);
 int32_t g16_prove_partials_end(g16_ctx* ctx, const g16_pkey* key, const void* d_a1_slice, const void* d_b1_slice,

@@ -9,7 +9,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 G16_OK, G16_EINVAL, G16_ENODEV, G16_EHIP, G16_ENOMEM, G16_ESELFTEST = 0, -1, -2, -3, -4, -5
-SCALARS_MONT, SCALARS_STD, SCALARS_DEVICE, OUT_PARTIAL, OUT_DEVICE = 1, 0, 2, 4, 8
+SCALARS_MONT, SCALARS_STD, SCALARS_DEVICE, OUT_PARTIAL, OUT_DEVICE, NO_HOST_SYNC = 1, 0, 2, 4, 8, 32
 PARTIALS_BYTES = 768
 
 # every symbol include/g16hip.h declares (checked by tests/test_abi.py)
@@ -329,22 +329,25 @@ class ProvingKey:
         return buf.raw
 
     def prove_partials_begin(self, witness, task_mask: int, task_out=None, mont: bool = True, device: bool = False,
-                             ctx=None):
+                             ctx=None, nosync: bool = False):
         """first half of a sharded proof with a task-parallel quotient: launches this key's witness MSMs and writes
-        the coset vectors named by task_mask (bit 0: A, 1: B, 2: C) to the device pointer task_out"""
+        the coset vectors named by task_mask (bit 0: A, 1: B, 2: C) to the device pointer task_out.  nosync: do not
+        wait for the coset vectors on the host (G16_NO_HOST_SYNC: the caller orders its exchange behind them through
+        the context's stream)"""
         c = ctx or self.ctx
         self._check_len(witness)
-        flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0)
+        flags = (SCALARS_MONT if mont else 0) | (SCALARS_DEVICE if device else 0) | (NO_HOST_SYNC if nosync else 0)
         c._check(c._lib.g16_prove_partials_begin(c._h, self._h, _buf(witness), flags, task_mask,
                                                  _buf(task_out) if task_out is not None else None))
 
-    def prove_partials_end(self, a1, b1, c1, out=None, ctx=None):
+    def prove_partials_end(self, a1, b1, c1, out=None, ctx=None, nosync: bool = False):
         """second half: a1 / b1 / c1 = device pointers to this key's [h_lo, h_hi) slices of the three coset vectors
         (None for an empty range); -> the 768-byte record (or written to the device pointer `out`)"""
         c = ctx or self.ctx
         ptr = lambda x: _buf(x) if x is not None else None          # noqa: E731
         if out is not None:
-            c._check(c._lib.g16_prove_partials_end(c._h, self._h, ptr(a1), ptr(b1), ptr(c1), OUT_DEVICE, _buf(out)))
+            c._check(c._lib.g16_prove_partials_end(c._h, self._h, ptr(a1), ptr(b1), ptr(c1),
+                                                   OUT_DEVICE | (NO_HOST_SYNC if nosync else 0), _buf(out)))
             return None
         buf = ctypes.create_string_buffer(PARTIALS_BYTES)
         c._check(c._lib.g16_prove_partials_end(c._h, self._h, ptr(a1), ptr(b1), ptr(c1), 0, buf))

@@ -106,8 +106,34 @@ inline void ctx_quiesce(g16_ctx* ctx) {
     if (l.stream) (void)hipStreamSynchronize(l.stream);
 }
 
+// Entry protocol of every context-taking C-ABI function.
+//  * The calling thread's current HIP device becomes the context's: allocations, event creation and launches bind to
+//    the CURRENT device, and a host thread starts on device 0 -- a context of GPU 3 used from a fresh worker thread
+//    would otherwise allocate its workspaces on GPU 0.
+//  * A g16_prove_partials_begin whose _end never came (the caller's exchange failed, or it simply moved on) still has
+//    four witness lanes reading the sort and per-proof buffers: any other compute call on the context first drains
+//    them and cancels the pending proof (its _end then returns G16_EINVAL).  `keep_shard`: calls that do not touch
+//    the workspaces (_end itself, synchronize, the profiling getters).
+inline int32_t ctx_enter(g16_ctx* ctx, bool keep_shard = false) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->shard_begun && !keep_shard) {
+    ctx_quiesce(ctx);
+    ctx->shard_begun = nullptr;
+  }
+  return G16_OK;
+}
+#define CTX_ENTER(ctx)                              \
+  do {                                              \
+    if (int32_t rc__ = ctx_enter(ctx)) return rc__; \
+  } while (0)
+#define CTX_ENTER_KEEP(ctx)                               \
+  do {                                                    \
+    if (int32_t rc__ = ctx_enter(ctx, true)) return rc__; \
+  } while (0)
+
 inline int32_t ensure(g16_ctx* ctx, g16_ctx::Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return G16_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));   // hipMalloc binds to the calling thread's current device
   if (b.p) {
     ctx_quiesce(ctx);
     HIPCHK(ctx, hipFree(b.p));

@@ -119,6 +119,7 @@ extern "C" const char* g16_last_error(const g16_ctx* ctx) { return ctx ? ctx->er
 
 extern "C" int32_t g16_ctx_set_stream(g16_ctx* ctx, void* hip_stream) {
   if (!ctx) return G16_EINVAL;
+  CTX_ENTER(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream) {
     (void)hipStreamDestroy(ctx->stream);
@@ -135,6 +136,7 @@ extern "C" int32_t g16_ctx_set_stream(g16_ctx* ctx, void* hip_stream) {
 
 extern "C" int32_t g16_ctx_synchronize(g16_ctx* ctx) {
   if (!ctx) return G16_EINVAL;
+  CTX_ENTER_KEEP(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return G16_OK;
 }
@@ -147,6 +149,7 @@ extern "C" int32_t g16_profile_enable(g16_ctx* ctx, int32_t on) {
 }
 extern "C" int32_t g16_profile_reset(g16_ctx* ctx) {
   if (!ctx) return G16_EINVAL;
+  CTX_ENTER_KEEP(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (auto& e : ctx->prof) {
     ctx->free_events.push_back(e.e0);
@@ -157,6 +160,7 @@ extern "C" int32_t g16_profile_reset(g16_ctx* ctx) {
 }
 extern "C" int32_t g16_profile_report(g16_ctx* ctx, char* buf, size_t buflen) {
   if (!ctx || !buf || buflen < 3) return G16_EINVAL;
+  CTX_ENTER_KEEP(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   std::map<std::string, std::pair<int, double>> agg;
   for (auto& e : ctx->prof) {
@@ -194,7 +198,7 @@ static int32_t msm_entry(g16_ctx* ctx, const void* scalars, uint32_t flags, cons
     ctx->err = "n too large (must be < 2^27)";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t out_bytes = partial ? sizeof(typename C::Acc) : sizeof(typename C::Aff);
   if (n == 0) {  // msm.nim:117: the sum starts from infG1 / infG2 = (0,0); XYZZ infinity is all-zero as well
     memset(out, 0, out_bytes);
@@ -232,7 +236,7 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
     return G16_EINVAL;
   }
   *out = nullptr;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   g16_points* h = new (std::nothrow) g16_points();
   if (!h) return G16_ENOMEM;
   h->device = ctx->device;
@@ -314,7 +318,7 @@ static int32_t points_check(g16_ctx* ctx, int group, const void* points, size_t 
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t psz = group == 1 ? 64 : 128;
   int32_t rc;
   if ((rc = ensure(ctx, ctx->stage_p, n * psz + psz))) return rc;
@@ -345,7 +349,7 @@ static int32_t fixed_base(g16_ctx* ctx, int group, const void* scalars, uint32_t
     ctx->err = "null pointer argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t psz = group == 1 ? 64 : 128;
   int32_t rc;
   g16_ctx::Buf& tb = ctx->fb_table[group - 1];
@@ -377,7 +381,7 @@ extern "C" int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const voi
     ctx->err = "bad argument (null pointer or point set of another device)";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const bool partial = (flags & G16_OUT_PARTIAL) != 0;
   const size_t psz = pts->group == 1 ? 64 : 128;
   const size_t out_bytes = partial ? 2 * psz : psz;
@@ -432,7 +436,7 @@ static int32_t sum_partials(g16_ctx* ctx, const void* xyzz, size_t count, void* 
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   int32_t rc;
   size_t bytes = count * sizeof(typename C::Acc);
   if ((rc = ensure(ctx, ctx->stage_p, bytes + 256))) return rc;
@@ -459,7 +463,7 @@ extern "C" int32_t g16_ntt_fr_dev(g16_ctx* ctx, const void* d_src, void* d_dst, 
     ctx->err = "bad argument (null pointer or log2n > 28)";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   return g16_ntt_device(ctx, d_src, d_dst, log2n, inverse ? 1 : 0);
 }
 
@@ -469,7 +473,7 @@ extern "C" int32_t g16_ntt_fr(g16_ctx* ctx, const void* src, void* dst, uint32_t
     ctx->err = "bad argument (null pointer or log2n > 28)";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t bytes = (size_t(1) << log2n) * 32;
   int32_t rc;
   if ((rc = ensure(ctx, ctx->stage_s, bytes))) return rc;
@@ -526,7 +530,7 @@ __global__ void selftest_kernel(uint32_t* out) {
 extern "C" int32_t g16_selftest(g16_ctx* ctx) {
   if (!ctx) return G16_EINVAL;
   static_assert(sizeof(u256) == 32 && sizeof(g1_aff) == 64 && sizeof(g2_aff) == 128, "layout");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   int32_t rc;
   g16_ctx::Buf st;   // own scratch: the MSM / NTT below use the context's staging buffers
   if ((rc = ensure(ctx, st, 4096))) return rc;

@@ -1,4 +1,7 @@
 // Launch sequences of the NTT passes and of the quotient pipeline built from them.
+#include <atomic>
+#include <mutex>
+
 #include "g16_internal.hpp"
 #include "ntt.cuh"
 
@@ -20,10 +23,15 @@ static int32_t ensure_twiddles(g16_ctx* ctx, uint32_t log2n) {
 // opted in once per process.
 static size_t pass_shmem(uint32_t rho, uint32_t log2b) { return (size_t(32) << (rho + log2b)) + (size_t(16) << rho); }
 static int32_t ntt_kernels_init(g16_ctx* ctx) {
-  static bool done_on[64] = {};   // per device (the attribute belongs to the device's copy of the code object);
-                                  // benign race: setting it twice is idempotent
-  bool& done = done_on[ctx->device & 63];
-  if (done) return G16_OK;
+  // per device (the attribute belongs to the device's copy of the code object).  Contexts of one device are used from
+  // several host threads at once (the in-flight proofs of bench.py): the flag is published with release semantics
+  // only after all four opt-ins succeeded, and the opt-ins themselves are serialised.
+  static std::atomic<bool> done_on[64];
+  static std::mutex mu;
+  std::atomic<bool>& done = done_on[ctx->device & 63];
+  if (done.load(std::memory_order_acquire)) return G16_OK;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.load(std::memory_order_relaxed)) return G16_OK;
   const int max_shmem = (int)pass_shmem(NTT_MAX_RHO, 2);
   static_assert((size_t(32) * NTT_TILE) + (size_t(16) << NTT_MAX_RHO) <= 160 * 1024, "tile + twiddles must fit the LDS");
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass<NTT_BLOCK>),
@@ -34,7 +42,7 @@ static int32_t ntt_kernels_init(g16_ctx* ctx) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_last_pass_abc<NTT_BLOCK_MID, NTT_TILE_MID>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
-  done = true;
+  done.store(true, std::memory_order_release);
   return G16_OK;
 }
 

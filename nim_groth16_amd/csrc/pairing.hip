@@ -150,7 +150,7 @@ extern "C" int32_t g16_pairing(g16_ctx* ctx, const void* g1_points, const void* 
     return G16_EINVAL;
   }
   if (!n) return G16_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   int32_t rc;
   const size_t o_q = n * 64, o_out = o_q + n * 128;
   if ((rc = ensure(ctx, ctx->stage_p, o_out + n * sizeof(fp12_t)))) return rc;
@@ -171,7 +171,7 @@ extern "C" int32_t g16_vkey_create(g16_ctx* ctx, const g16_vkey_desc* d, g16_vke
     ctx->err = "g16_vkey_create: bad descriptor";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   g16_vkey* k = new (std::nothrow) g16_vkey();
   if (!k) return G16_ENOMEM;
   k->device = ctx->device;
@@ -222,7 +222,7 @@ extern "C" int32_t g16_verify(g16_ctx* ctx, const g16_vkey* key, const g16_proof
     return G16_EINVAL;
   }
   if (!count) return G16_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t nio = (size_t)key->npubs + 1, total = count * nio;
   size_t o = 0;
   auto take = [&](size_t bytes) {

@@ -129,7 +129,7 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
     ctx->err = "bad proving-key description";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   g16_pkey* k = new (std::nothrow) g16_pkey();
   if (!k) return G16_ENOMEM;
   k->device = ctx->device;
@@ -234,7 +234,7 @@ extern "C" int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* k, const void* wi
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t n = size_t(1) << k->log2n;
   int32_t rc;
   if ((rc = ensure(ctx, ctx->prove, ((size_t)k->nvars + 4 * n) * 32))) return rc;
@@ -261,7 +261,7 @@ extern "C" int32_t g16_prove_partials(g16_ctx* ctx, const g16_pkey* k, const voi
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const int32_t rc = prove_partials_impl(ctx, k, witness, flags, out_partials);
   // an error exit may leave work queued on the lane streams (e.g. a failed allocation after the witness MSMs were
   // launched): drain all of them before returning, so that the caller -- or the next call's ensure() -- can never
@@ -354,7 +354,9 @@ static int32_t launch_h_and_collect(g16_ctx* ctx, const g16_pkey* k, const u256*
     for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->lane[i].done, 0));
   HIPCHK(ctx, hipMemcpyAsync(out_partials, b.slots, PART_BYTES,
                              (flags & G16_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  // G16_NO_HOST_SYNC (device output only): the record is complete in stream order; the caller's next operation on
+  // the context's stream (an all-gather enqueued on it, g16_prove_combine) is ordered behind it without a host wait
+  if (!((flags & G16_NO_HOST_SYNC) && (flags & G16_OUT_DEVICE))) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return G16_OK;
 }
 
@@ -413,7 +415,7 @@ extern "C" int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* k, con
                "vector: use g16_prove_partials)";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t n = size_t(1) << k->log2n;
   ProveBufs b;
   int32_t rc = prove_bufs(ctx, k, b);
@@ -433,7 +435,7 @@ extern "C" int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* k, con
     after = ctx->ev_q;
   }
   if (!rc) rc = launch_witness_msms(ctx, k, flags, b, after);
-  if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // the task outputs are complete; the lanes run on
+  if (!rc && !(flags & G16_NO_HOST_SYNC) && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // the task outputs are complete; the lanes run on
     ctx->err = "hipStreamSynchronize failed";
     rc = G16_EHIP;
   }
@@ -457,8 +459,8 @@ extern "C" int32_t g16_prove_partials_end(g16_ctx* ctx, const g16_pkey* k, const
     ctx->err = "g16_prove_partials_end without a matching g16_prove_partials_begin on this context";
     return G16_EINVAL;
   }
+  CTX_ENTER_KEEP(ctx);
   ctx->shard_begun = nullptr;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   ProveBufs b;
   int32_t rc = prove_bufs(ctx, k, b);
   if (!rc) rc = g16_abc_pointwise_device(ctx, d_a1, d_b1, d_c1, nh, b.d_qs);
@@ -493,7 +495,7 @@ extern "C" int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* k, const void
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   int32_t rc;
   if ((rc = ensure(ctx, ctx->stage_p, count * PART_BYTES))) return rc;
   if ((rc = ensure(ctx, ctx->stage_o, 2048))) return rc;
@@ -549,6 +551,7 @@ extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witnes
     ctx->err = "g16_prove needs an unsharded key; use g16_prove_partials + g16_prove_combine";
     return G16_EINVAL;
   }
+  CTX_ENTER(ctx);   // before the first allocation: a fresh host thread's current device is 0, not the context's
   int32_t rc;
   if ((rc = ensure(ctx, ctx->stage_o, 2048))) return rc;
   if ((rc = ensure(ctx, ctx->stage_s, PART_BYTES))) return rc;
@@ -566,7 +569,7 @@ extern "C" int32_t g16_quotient(g16_ctx* ctx, const void* Az, const void* Bz, co
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   const size_t n = size_t(1) << log2n;
   int32_t rc;
   if ((rc = ensure(ctx, ctx->prove, 4 * n * 32))) return rc;
@@ -586,6 +589,6 @@ extern "C" int32_t g16_quotient_dev(g16_ctx* ctx, const void* d_Az, const void* 
     ctx->err = "bad argument";
     return G16_EINVAL;
   }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CTX_ENTER(ctx);
   return g16_quotient_device(ctx, d_Az, d_Bz, d_Cz, log2n, (int)flavour, d_out);
 }

@@ -75,9 +75,11 @@ class ShardedProver:
         else:
             vec = task_out.cpu() if (cpu_group and owned) else task_out
             for v in range(3):      # the exchange: owner(v) hands every rank its slice of coset vector v
-                src = quotientTaskOwner(v, world)
+                owner = quotientTaskOwner(v, world)
+                # dist.scatter takes a GLOBAL rank as src; owner is a rank of `self.group`
+                src = self.dist.get_global_rank(self.group, owner) if self.group is not None else owner
                 chunks = None
-                if rank == src:
+                if rank == owner:
                     base = 32 * n * owned.index(v)
                     chunks = []
                     for lo, hi in ranges:

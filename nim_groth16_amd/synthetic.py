@@ -56,3 +56,41 @@ def squaringChain(m: int, seed: int = 4, w0: int = 3):
         cons.append(([(wire(i), 1)], [(wire(i), 1)], [(wire(i + 1), 1), (0, (-ks[i]) % R)]))
     witness = [1, w[m]] + w[:m]
     return R1CS(nWires=m + 2, nPubOut=1, nPubIn=0, nPrivIn=1, constraints=cons), witness
+
+
+def mixedCircuit(m: int, seed: int = 4, zero_pct: int = 40, one_pct: int = 30, lin_pct: int = 0, w0: int = 3):
+    """A circuit whose witness looks like a circom witness (SURVEY 8d config 2-ii / config 5's shape) instead of the
+    squaring chain's full-width values.  Same wire layout as squaringChain -- [1, v_m (public), v_0 .. v_(m-1)],
+    constraint i defines v_(i+1) -- with four kinds of constraint, drawn per row from SplitMix64(seed + 1000):
+      zero_pct %  boolean wire holding 0:  b * b = b
+      one_pct  %  boolean wire holding 1:  b * b = b
+      lin_pct  %  linear step  (cur + k_i) * 1 = new  -- `cur` enters A only, so a wire that is only ever used in
+                  linear steps is ABSENT FROM B and its pointsB1 / pointsB2 entries are the point at infinity (0,0),
+                  as snarkjs keys have them for such wires (zkey.nim loads them as they are, curves.nim:95-98)
+      the rest    squaring step  cur * cur = new - k_i  (full-width values)
+    The last row is always a squaring step (it defines the public output).  -> (R1CS, witness values as ints)."""
+    ks = _fr_stream(seed, m)
+    kind = SplitMix64(seed + 1000)
+
+    def wire(i):
+        return i + 2 if i < m else 1
+    cons = []
+    v = [0] * (m + 1)
+    v[0] = w0 % R
+    cur = 0                                    # index of the latest full-width value
+    for i in range(m):
+        u = kind.next() % 100 if i + 1 < m else 100
+        new = wire(i + 1)
+        if u < zero_pct + one_pct:
+            v[i + 1] = 0 if u < zero_pct else 1
+            cons.append(([(new, 1)], [(new, 1)], [(new, 1)]))
+        elif u < zero_pct + one_pct + lin_pct:
+            v[i + 1] = (v[cur] + ks[i]) % R
+            cons.append(([(wire(cur), 1), (0, ks[i])], [(0, 1)], [(new, 1)]))
+            cur = i + 1
+        else:
+            v[i + 1] = (v[cur] * v[cur] + ks[i]) % R
+            cons.append(([(wire(cur), 1)], [(wire(cur), 1)], [(new, 1), (0, (-ks[i]) % R)]))
+            cur = i + 1
+    witness = [1, v[m]] + v[:m]
+    return R1CS(nWires=m + 2, nPubOut=1, nPubIn=0, nPrivIn=1, constraints=cons), witness

@@ -135,3 +135,90 @@ def test_verifier_rejects_non_canonical_encodings(ctx):
     std = I.fr_std_bytes(I.fr_from_mont(good.publicIO))
     assert dev.verify([tri], std, mont=False) == [1]
     assert dev.verify([tri], plus(std, 32, o.R), mont=False) == [-6]
+
+
+def _small_key(ctx, log2n=10, **shard):
+    from nim_groth16_amd import loadProvingKey
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import SplitMix64, squaringChain
+    r1cs, wit = squaringChain((1 << log2n) - 2, seed=4)
+    rng = SplitMix64(5)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
+    return zk, loadProvingKey(zk, ctx, **shard), F.frSeqToMontBytes(wit)
+
+
+def test_pending_begin_is_cancelled_by_any_other_call(ctx):
+    """include/g16hip.h: between g16_prove_partials_begin and _end the witness lanes run on the context's sort and
+    per-proof buffers; any other compute call first drains them and cancels the pending proof -- round 2 let a second
+    call rewrite the offsets the lanes were still reading.  The sequence
+    begin -> prove_partials (same context) -> end  must leave a correct record and a clean G16_EINVAL."""
+    import torch
+    from nim_groth16_amd._lib import G16_EINVAL, G16Error
+    zk, pk, wb = _small_key(ctx, 12)
+    n = zk.header.domainSize
+    try:
+        want = pk.prove_partials(wb)
+        out = torch.empty(3 * n * 32, dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            pk.prove_partials_begin(wb, 7, out.data_ptr())
+            assert pk.prove_partials(wb) == want           # cancels the begin, then computes on the drained context
+            with pytest.raises(G16Error) as e:
+                pk.prove_partials_end(out.data_ptr(), out.data_ptr() + 32 * n, out.data_ptr() + 64 * n)
+            assert e.value.code == G16_EINVAL
+        # and the regular pair still works afterwards: begin (all three pipelines here) -> end == replicated record
+        pk.prove_partials_begin(wb, 7, out.data_ptr())
+        assert pk.prove_partials_end(out.data_ptr(), out.data_ptr() + 32 * n, out.data_ptr() + 64 * n) == want
+        # the no-host-sync variant, ordered by the context's stream alone
+        rec = torch.empty(768, dtype=torch.uint8, device="cuda")
+        pk.prove_partials_begin(wb, 7, out.data_ptr(), nosync=True)
+        pk.prove_partials_end(out.data_ptr(), out.data_ptr() + 32 * n, out.data_ptr() + 64 * n, out=rec.data_ptr(),
+                              nosync=True)
+        ctx.synchronize()
+        assert bytes(rec.cpu().numpy()) == want
+    finally:
+        pk.destroy()
+
+
+def test_prove_from_a_fresh_host_thread(ctx):
+    """every C-ABI call makes the context's device the calling thread's current device (ctx_enter): a new host thread
+    starts on device 0, and round 2's g16_prove allocated its result slots before setting the device (ADVICE r02,
+    high).  One GPU cannot tell the devices apart, so this covers the thread path; the two-GPU case below runs when
+    the box has a second device."""
+    zk, pk, wb = _small_key(ctx, 10)
+    try:
+        want = pk.prove(wb)
+        got = []
+        th = threading.Thread(target=lambda: got.append(pk.prove(wb)))
+        th.start()
+        th.join()
+        assert got == [want]
+    finally:
+        pk.destroy()
+
+
+def test_context_of_second_gpu_from_a_thread_on_device_zero():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from nim_groth16_amd import Context
+    c0, c1 = Context(0), Context(1)
+    zk, pk0, wb = _small_key(c0, 10)
+    _, pk1, _ = _small_key(c1, 10)
+    try:
+        want = pk0.prove(wb)
+        got = []
+
+        def work():                      # this thread's current device is 0; the context lives on device 1
+            c = Context(1)
+            got.append(pk1.prove(wb, ctx=c))
+            c.close()
+        th = threading.Thread(target=work)
+        th.start()
+        th.join()
+        assert got == [want]
+    finally:
+        pk0.destroy()
+        pk1.destroy()
+        c0.close()
+        c1.close()
