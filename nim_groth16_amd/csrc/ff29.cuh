@@ -16,6 +16,8 @@
 // registration (Ec29::tab_from_std, packed 64/128-byte entries) and the 16-bucket chunk sums are converted back
 // to the 8x32 / R=2^256 layout of ff.cuh (Ec29::to_std) before the latency-bound tail (reduce2, fold) sees them.
 #pragma once
+#include <utility>
+
 #include "ff.cuh"
 
 // Every multiply-add of a column is pinned behind the previous one by an empty (non-volatile) asm, so that the
@@ -42,6 +44,8 @@ namespace g16 {
 struct fe29 {
   uint32_t v[9];
 };
+
+#include "ff29_mac.inc"
 
 struct Fp29 {
   static constexpr int B = 29, L = 9;
@@ -103,11 +107,92 @@ struct Fp29 {
     return o == 0;
   }
 
+  // ---- column chains as single asm statements (-DG16_F29_ASM: the G1 accumulate kernel) ----------------------
+  // Column k of a product: the a_i*b_(k-i) for i = lo..hi, then the m_i*p_(k-i) of the interleaved Montgomery
+  // reduction.  Each part is ONE asm statement of back-to-back v_mad_u64_u32 on the same accumulator
+  // (ff29_mac.inc): a serial chain without the compiler's per-column join add, like the pins of F29_MAC, but
+  // with one hipcc s_nop per statement instead of one per product.
+  template <int K>
+  static constexpr int col_lo() { return K < L ? 0 : K - L + 1; }
+  template <int K>
+  static constexpr int col_cnt() { return K < L ? K + 1 : 2 * L - 1 - K; }   // products a_i*b_(K-i)
+  template <int K>
+  static constexpr int red_cnt() { return K < L ? K : 2 * L - 1 - K; }       // m_i*p_(K-i) with m_i already known
+  template <int K, int... I>
+  static FF_HD void col_mul(uint64_t& acc, const fe29& a, const fe29& b, std::integer_sequence<int, I...>) {
+    mac29v(acc, a.v[col_lo<K>() + I]..., b.v[K - col_lo<K>() - I]...);
+  }
+  template <int K, int... I>
+  static FF_HD void col_red(uint64_t& acc, const uint32_t (&m)[L], std::integer_sequence<int, I...>) {
+    mac29s(acc, m[col_lo<K>() + I]..., PL.v[K - col_lo<K>() - I]...);
+  }
+  // squaring: the products i < K-i against the doubled operand, i == K-i against itself
+  template <int K, int I>
+  static FF_HD uint32_t sqr_rhs(const fe29& a, const uint32_t (&a2)[L]) {
+    constexpr int i = col_lo<K>() + I, j = K - i;
+    static_assert(i <= j, "upper triangle");
+    return i == j ? a.v[j] : a2[j];
+  }
+  template <int K, int... I>
+  static FF_HD void col_sqr(uint64_t& acc, const fe29& a, const uint32_t (&a2)[L], std::integer_sequence<int, I...>) {
+    mac29v(acc, a.v[col_lo<K>() + I]..., sqr_rhs<K, I>(a, a2)...);
+  }
+  template <int K>
+  static FF_HD void col_finish(uint64_t& acc, uint32_t (&m)[L], fe29& r) {
+    if constexpr (red_cnt<K>() > 0) col_red<K>(acc, m, std::make_integer_sequence<int, red_cnt<K>()>{});
+    if constexpr (K < L) {
+      m[K] = ((uint32_t)acc * N0) & MASK;
+      acc += (uint64_t)m[K] * PL.v[0];
+    } else {
+      r.v[K - L] = (uint32_t)acc & MASK;
+    }
+    acc >>= B;
+  }
+  template <int NP, int K>
+  static FF_HD void dot_col(uint64_t& acc, uint32_t (&m)[L], fe29& r, const fe29& a0, const fe29& b0, const fe29& a1,
+                            const fe29& b1, const fe29& a2, const fe29& b2, const fe29& a3, const fe29& b3) {
+    using Seq = std::make_integer_sequence<int, col_cnt<K>()>;
+    col_mul<K>(acc, a0, b0, Seq{});
+    if constexpr (NP > 1) col_mul<K>(acc, a1, b1, Seq{});
+    if constexpr (NP > 2) col_mul<K>(acc, a2, b2, Seq{});
+    if constexpr (NP > 3) col_mul<K>(acc, a3, b3, Seq{});
+    col_finish<K>(acc, m, r);
+  }
+  template <int NP, int... K>
+  static FF_HD fe29 dot_asm(const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1, const fe29& a2,
+                            const fe29& b2, const fe29& a3, const fe29& b3, std::integer_sequence<int, K...>) {
+    uint32_t m[L];
+    fe29 r;
+    uint64_t acc = 0;
+    (dot_col<NP, K>(acc, m, r, a0, b0, a1, b1, a2, b2, a3, b3), ...);
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+  }
+  template <int K>
+  static FF_HD void sqr_col(uint64_t& acc, uint32_t (&m)[L], fe29& r, const fe29& a, const uint32_t (&a2)[L]) {
+    col_sqr<K>(acc, a, a2, std::make_integer_sequence<int, (col_cnt<K>() + 1) / 2>{});
+    col_finish<K>(acc, m, r);
+  }
+  template <int... K>
+  static FF_HD fe29 sqr_asm(const fe29& a, std::integer_sequence<int, K...>) {
+    uint32_t m[L], a2[L];
+    fe29 r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) a2[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+    (sqr_col<K>(acc, m, r, a, a2), ...);
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+  }
+
   // (sum over NP pairs of a_j*b_j) / 2^261 mod p.  Every 64-bit column sum must stay below 2^64: with limb
   // bounds la_j, lb_j that is  9*(sum_j la_j*lb_j + 2^58) < 2^64.  Result: normalized, < (sum a_j b_j)/2^261 + p.
   template <int NP>
   static FF_HD fe29 dot(const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1, const fe29& a2,
                         const fe29& b2, const fe29& a3, const fe29& b3) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_F29_ASM)
+    return dot_asm<NP>(a0, b0, a1, b1, a2, b2, a3, b3, std::make_integer_sequence<int, 2 * L - 1>{});
+#endif
     uint32_t m[L];
     fe29 r;
     uint64_t acc = 0;
@@ -190,6 +275,9 @@ struct Fp29 {
   }
   // a^2 / 2^261: the cross products once, against the doubled operand (45 + 81 multiply-adds instead of 162)
   static FF_HD fe29 sqr(const fe29& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_F29_ASM)
+    return sqr_asm(a, std::make_integer_sequence<int, 2 * L - 1>{});
+#endif
     uint32_t m[L], a2[L];
     fe29 r;
 #pragma unroll

@@ -31,38 +31,35 @@ constexpr int ACC_BLOCK = G16_ACC_BLOCK;   // workgroup size of the accumulate k
 constexpr int FR_BITS = 254;
 
 
-// canonical scalar limbs into LDS (layout [limb][thread]: conflict-free), then signed digits
+// signed c-bit digits of a scalar, least significant window first.  The canonical scalar stays in its 8 registers
+// and is shifted right by c bits per window (8 funnel shifts with static register indices, c <= 22 < 32): no LDS
+// staging, no dynamic limb indexing, and any workgroup size.  (Rounds 1-2 staged the limbs in LDS and indexed them by
+// window: 36 KB of LDS per 1024 threads and two LDS reads per digit.)
 template <class EMIT>
-__device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, uint32_t i, const MsmParams& P,
-                                           uint32_t* lds_limbs, EMIT&& emit) {
+__device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, uint32_t i, const MsmParams& P, EMIT&& emit) {
   u256 s = scalars[i];
   if (P.scalars_mont) s = Fr::from_mont(s);
   if (Fr::is_zero(s)) return;
-  const uint32_t tid = threadIdx.x;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) lds_limbs[j * MSM_BLOCK + tid] = s.v[j];
-  lds_limbs[8 * MSM_BLOCK + tid] = 0;
   const uint32_t c = P.c, half = 1u << (c - 1), mask = (1u << c) - 1;
   uint32_t carry = 0;
   for (uint32_t w = 0; w < P.nwin; ++w) {
-    uint32_t bit = w * c, idx = bit >> 5, sh = bit & 31;
-    uint64_t two = (uint64_t)lds_limbs[idx * MSM_BLOCK + tid] |
-                   ((uint64_t)lds_limbs[(idx + 1) * MSM_BLOCK + tid] << 32);
-    uint32_t raw = ((uint32_t)(two >> sh) & mask) + carry;
+    uint32_t raw = (s.v[0] & mask) + carry;
     uint32_t neg = raw > half ? 1u : 0u;
     uint32_t mag = neg ? (1u << c) - raw : raw;
     carry = neg;
     if (mag) emit(w, mag - 1, neg);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s.v[j] = __builtin_amdgcn_alignbit(s.v[j + 1], s.v[j], c);
+    s.v[7] >>= c;
   }
 }
 
 static __global__ void __launch_bounds__(MSM_BLOCK) msm_count(const u256* __restrict__ scalars, MsmParams P,
                                                        uint32_t* __restrict__ count) {
-  __shared__ uint32_t limbs[9 * MSM_BLOCK];
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= P.n) return;
   const uint32_t bshift = P.c - 1;
-  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t) {
+  msm_digits(scalars, i, P, [&](uint32_t w, uint32_t k, uint32_t) {
     atomicAdd(&count[(P.tables ? 0u : (w << bshift)) + k], 1u);
   });
 }
@@ -71,11 +68,10 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __re
                                                          const uint32_t* __restrict__ offset,
                                                          uint32_t* __restrict__ cursor,
                                                          uint32_t* __restrict__ entries) {
-  __shared__ uint32_t limbs[9 * MSM_BLOCK];
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= P.n) return;
   const uint32_t bshift = P.c - 1;
-  msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t neg) {
+  msm_digits(scalars, i, P, [&](uint32_t w, uint32_t k, uint32_t neg) {
     uint32_t b = (P.tables ? 0u : (w << bshift)) + k;
     uint32_t pos = offset[b] + atomicAdd(&cursor[b], 1u);
     // entry = point index (table-major when tables are used) | sign in bit 31
@@ -118,8 +114,11 @@ __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* ctr, uint32_t key) {
   return atomicAdd(&ctr[key], 1u);
 }
 
-constexpr int PART_BLOCK = 256;
-constexpr int PART_PER_THREAD = 16;
+// 1024 threads x 4 scalars: the pass is a chain of dependent LDS atomics and scattered 8-byte stores per thread, and a
+// 2^20-scalar sort has only 256 tiles -- one workgroup per CU -- so the workgroup is as wide as it gets (16 waves per
+// CU hide that latency; rounds 1-2 ran 256 threads x 16 scalars = ONE wave per SIMD)
+constexpr int PART_BLOCK = 1024;
+constexpr int PART_PER_THREAD = 4;
 constexpr int PART_TILE = PART_BLOCK * PART_PER_THREAD;  // scalars per workgroup
 constexpr int PART_MAX = 8192;                           // max partitions (LDS histogram, 32 KB)
 
@@ -128,7 +127,6 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
                                                                uint32_t lo_bits, uint32_t nparts, uint32_t ntiles,
                                                                uint32_t* __restrict__ tile_hist,
                                                                uint2* __restrict__ tmp) {
-  __shared__ uint32_t limbs[9 * MSM_BLOCK];
   __shared__ uint32_t hist[PART_MAX];
   const uint32_t tile = blockIdx.x;
   for (uint32_t p = threadIdx.x; p < nparts; p += PART_BLOCK)
@@ -138,7 +136,7 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
   for (uint32_t r = 0; r < PART_PER_THREAD; ++r) {
     uint32_t i = tile * PART_TILE + r * PART_BLOCK + threadIdx.x;
     if (i < P.n) {
-      msm_digits(scalars, i, P, limbs, [&](uint32_t w, uint32_t k, uint32_t neg) {
+      msm_digits(scalars, i, P, [&](uint32_t w, uint32_t k, uint32_t neg) {
         uint32_t part = (P.tables ? 0u : (w << hi_bits)) | (k >> lo_bits);
         uint32_t pos = lds_rank_add(hist, part);
         if (SCATTER) tmp[pos] = make_uint2((k & lo_mask) | (neg << 8), P.tables ? w * P.n + i : i);
@@ -176,14 +174,25 @@ static __global__ void __launch_bounds__(256) bucket_hist(const uint2* __restric
   __syncthreads();
   slice_hist[(size_t)blockIdx.x * 256 + tid] = hist[tid];
 }
+// `fused` (lo_bits == 8: one partition = one 256-bucket block of the size-order permutation): the q == 0 workgroup of
+// every partition holds the final bucket counts in registers anyway, so it also does what rounds 1-2 ran five more
+// launches for -- the extra-segment bookkeeping of split buckets (xoff[], heavy list; split buckets are rare, so
+// their range of extra-segment slots comes from one global atomic each instead of a device-wide scan) and the size
+// histogram of the permutation (perm_hist).
+constexpr int PERM_BINS_ = 256;
+__device__ __forceinline__ uint32_t extra_segs_(uint32_t cnt, uint32_t L) { return cnt > L ? (cnt - 1) / L : 0u; }
 static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restrict__ tmp,
                                                            const uint32_t* __restrict__ part_base, uint32_t ntiles,
                                                            uint32_t nparts, const uint32_t* __restrict__ total,
                                                            const uint32_t* __restrict__ slice_hist, MsmParams P,
                                                            uint32_t lo_bits, uint32_t* __restrict__ count,
                                                            uint32_t* __restrict__ offset,
-                                                           uint32_t* __restrict__ entries) {
+                                                           uint32_t* __restrict__ entries, uint32_t fused,
+                                                           uint32_t* __restrict__ xoff, uint32_t* __restrict__ heavy,
+                                                           uint32_t* __restrict__ info, uint32_t* __restrict__ ghist,
+                                                           uint32_t* __restrict__ blk_base) {
   __shared__ uint32_t cur[256];
+  __shared__ uint32_t szh[PERM_BINS_];
   const uint32_t part = blockIdx.x / BS_SPLIT, q = blockIdx.x % BS_SPLIT, tid = threadIdx.x;
   const uint32_t start = part_base[(size_t)part * ntiles];
   const uint32_t end = part + 1 < nparts ? part_base[(size_t)(part + 1) * ntiles] : total[0];
@@ -197,6 +206,7 @@ static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restri
   }
   // exclusive scan of the 256 bucket totals (Hillis-Steele in LDS)
   cur[tid] = mine;
+  szh[tid] = 0;
   __syncthreads();
   for (int d = 1; d < 256; d <<= 1) {
     uint32_t add = (int)tid >= d ? cur[tid - d] : 0u;
@@ -213,10 +223,24 @@ static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restri
       uint32_t b = (part << lo_bits) + tid;
       count[b] = mine;
       offset[b] = start + excl;
+      if (fused) {
+        const uint32_t e = extra_segs_(mine, P.seg);
+        uint32_t x0 = 0;
+        if (e) {
+          x0 = atomicAdd(&info[1], e);
+          heavy[atomicAdd(&info[2], 1u)] = b;
+        }
+        xoff[b] = x0;
+        atomicAdd(&szh[mine < PERM_BINS_ - 1 ? mine : PERM_BINS_ - 1], 1u);
+      }
     }
     if (part == nparts - 1 && tid == 0) offset[P.nbuckets] = end;
   }
   __syncthreads();
+  if (q == 0 && fused) {
+    const uint32_t m = szh[tid];
+    blk_base[(size_t)part * PERM_BINS_ + tid] = m ? atomicAdd(&ghist[tid], m) : 0u;
+  }
   uint32_t lo, hi;
   bs_slice(start, end, q, lo, hi);
   for (uint32_t j = lo + tid; j < hi; j += 256) {

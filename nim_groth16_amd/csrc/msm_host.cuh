@@ -106,7 +106,10 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   S.tiles2 = (uint2*)(ws + o_tiles2);
   S.slice_hist = (uint32_t*)(ws + o_shist);
   const auto* scalars = (const u256*)d_scalars;
-  HIPCHK(ctx, hipMemsetAsync(ws + o_count, 0, o_offset - o_count, st));  // count + cursor are adjacent
+  // lo_bits == 8: bucket_place also produces xoff / heavy / the size histogram (see msm.cuh); count[] and offset[] are
+  // fully written by it, so the partition path clears only the two small counter blocks
+  const bool fused = use_part && lo_bits == 8;
+  if (!use_part) HIPCHK(ctx, hipMemsetAsync(ws + o_count, 0, o_offset - o_count, st));  // count + cursor are adjacent
   HIPCHK(ctx, hipMemsetAsync(S.info, 0, 64, st));
   HIPCHK(ctx, hipMemsetAsync(S.ghist, 0, PERM_BINS * 4, st));
   const uint32_t nblk = (P.n + MSM_BLOCK - 1) / MSM_BLOCK;
@@ -123,16 +126,19 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
     KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_hist, nparts * BS_SPLIT, 256, 0, S.tmp, S.tile_hist, ptiles, nparts,
                S.info + 8, S.slice_hist);
     KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_place, nparts * BS_SPLIT, 256, 0, S.tmp, S.tile_hist, ptiles, nparts,
-               S.info + 8, S.slice_hist, P, lo_bits, S.count, S.offset, S.entries);
+               S.info + 8, S.slice_hist, P, lo_bits, S.count, S.offset, S.entries, fused ? 1u : 0u, S.xoff, S.heavy,
+               S.info, S.ghist, S.blk_base);
   } else {
     KLAUNCH_ON(ctx, st, "msm_count", msm_count, nblk, MSM_BLOCK, 0, scalars, P, S.count);
   }
-  KLAUNCH_ON(ctx, st, "msm_scan", scan_tile_sums, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles);
-  KLAUNCH_ON(ctx, st, "msm_scan", scan_tiles, 1, SCAN_BLOCK, 0, S.tiles, ntiles, S.info);
-  KLAUNCH_ON(ctx, st, "msm_scan", scan_apply, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles, S.offset,
-             S.xoff, S.heavy, S.info);
   const uint32_t pblk = (P.nbuckets + PERM_BLOCK - 1) / PERM_BLOCK;
-  KLAUNCH_ON(ctx, st, "msm_perm", perm_hist, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base);
+  if (!fused) {
+    KLAUNCH_ON(ctx, st, "msm_scan", scan_tile_sums, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles);
+    KLAUNCH_ON(ctx, st, "msm_scan", scan_tiles, 1, SCAN_BLOCK, 0, S.tiles, ntiles, S.info);
+    KLAUNCH_ON(ctx, st, "msm_scan", scan_apply, ntiles, SCAN_BLOCK, 0, S.count, P.nbuckets, P.seg, S.tiles, S.offset,
+               S.xoff, S.heavy, S.info);
+    KLAUNCH_ON(ctx, st, "msm_perm", perm_hist, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base);
+  }
   KLAUNCH_ON(ctx, st, "msm_perm", perm_scatter, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base,
              S.perm);
   if (!use_part)

@@ -158,24 +158,28 @@ def test_pending_begin_is_cancelled_by_any_other_call(ctx):
     zk, pk, wb = _small_key(ctx, 12)
     n = zk.header.domainSize
     try:
-        want = pk.prove_partials(wb)
+        # XYZZ records are not canonical (the order of additions inside a bucket follows the LDS atomics of the sort):
+        # records are compared through the proof they combine to
+        fin = lambda rec: pk.prove_combine(rec, 1)           # noqa: E731
+        want = fin(pk.prove_partials(wb))
+        assert want == pk.prove(wb)
         out = torch.empty(3 * n * 32, dtype=torch.uint8, device="cuda")
         for _ in range(3):
             pk.prove_partials_begin(wb, 7, out.data_ptr())
-            assert pk.prove_partials(wb) == want           # cancels the begin, then computes on the drained context
+            assert fin(pk.prove_partials(wb)) == want      # cancels the begin, then computes on the drained context
             with pytest.raises(G16Error) as e:
                 pk.prove_partials_end(out.data_ptr(), out.data_ptr() + 32 * n, out.data_ptr() + 64 * n)
             assert e.value.code == G16_EINVAL
         # and the regular pair still works afterwards: begin (all three pipelines here) -> end == replicated record
         pk.prove_partials_begin(wb, 7, out.data_ptr())
-        assert pk.prove_partials_end(out.data_ptr(), out.data_ptr() + 32 * n, out.data_ptr() + 64 * n) == want
+        assert fin(pk.prove_partials_end(out.data_ptr(), out.data_ptr() + 32 * n, out.data_ptr() + 64 * n)) == want
         # the no-host-sync variant, ordered by the context's stream alone
         rec = torch.empty(768, dtype=torch.uint8, device="cuda")
         pk.prove_partials_begin(wb, 7, out.data_ptr(), nosync=True)
         pk.prove_partials_end(out.data_ptr(), out.data_ptr() + 32 * n, out.data_ptr() + 64 * n, out=rec.data_ptr(),
                               nosync=True)
         ctx.synchronize()
-        assert bytes(rec.cpu().numpy()) == want
+        assert fin(bytes(rec.cpu().numpy())) == want
     finally:
         pk.destroy()
 

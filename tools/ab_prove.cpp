@@ -1,0 +1,112 @@
+// ab_prove -- throughput of ONE build of libg16hip.so on a .zkey / .wtns pair, for paired same-box A/B runs of
+// several builds (tools/ab_rounds.sh).  The library is dlopen()ed from the path given with -l, so the very same
+// binary, key file, witness and protocol measure every build; only entry points that exist since round 1 are used
+// (g16_ctx_create, g16_pkey_create, g16_prove, g16_pkey_destroy, g16_ctx_destroy).
+//
+//   g++ -O2 -std=c++17 -Iinclude tools/ab_prove.cpp -ldl -lpthread -o ab_prove
+//   ./ab_prove -l path/to/libg16hip.so -z circuit.zkey -w witness.wtns [-k steps] [-f inflight] [-K] [-r reps]
+//
+// Protocol = bench.py's replica mode: `inflight` host threads, one context each, prove `steps` proofs in total from
+// the (host, .wtns-layout) witness; wall time over the whole batch; `reps` batches, each printed.  -K: one key per
+// context (round 1's ownership rule: a key belonged to the context that created it) instead of one shared key.
+#define G16_TOOL_NAME "ab_prove"
+#include <dlfcn.h>
+
+#include <atomic>
+#include <thread>
+
+#include "g16_files.hpp"
+
+int main(int argc, char** argv) {
+  const char *lpath = nullptr, *zpath = nullptr, *wpath = nullptr;
+  int steps = 96, inflight = 3, reps = 3;
+  bool key_per_ctx = false;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto next = [&]() -> const char* {
+      if (i + 1 >= argc) die("missing value after " + a);
+      return argv[++i];
+    };
+    if (a == "-l") lpath = next();
+    else if (a == "-z") zpath = next();
+    else if (a == "-w") wpath = next();
+    else if (a == "-k") steps = atoi(next());
+    else if (a == "-f") inflight = atoi(next());
+    else if (a == "-r") reps = atoi(next());
+    else if (a == "-K") key_per_ctx = true;
+    else die("unknown option " + a);
+  }
+  if (!lpath || !zpath || !wpath || steps < 1 || inflight < 1 || inflight > 16)
+    die("usage: ab_prove -l libg16hip.so -z circuit.zkey -w witness.wtns [-k steps] [-f inflight] [-K] [-r reps]");
+  void* lib = dlopen(lpath, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) die(std::string("dlopen: ") + dlerror());
+  auto sym = [&](const char* name) {
+    void* p = dlsym(lib, name);
+    if (!p) die(std::string("missing symbol ") + name);
+    return p;
+  };
+  auto ctx_create = (int32_t(*)(int32_t, g16_ctx**))sym("g16_ctx_create");
+  auto ctx_destroy = (void (*)(g16_ctx*))sym("g16_ctx_destroy");
+  auto last_error = (const char* (*)(const g16_ctx*))sym("g16_last_error");
+  auto pkey_create = (int32_t(*)(g16_ctx*, const g16_pkey_desc*, g16_pkey**))sym("g16_pkey_create");
+  auto pkey_destroy = (void (*)(g16_pkey*))sym("g16_pkey_destroy");
+  auto prove = (int32_t(*)(g16_ctx*, const g16_pkey*, const void*, uint32_t, const void*, const void*, g16_proof*))sym("g16_prove");
+
+  ZkeyFile zf(zpath);
+  WtnsFile wf(wpath, zf.nvars);
+  const g16_pkey_desc d = zf.desc();
+  std::vector<g16_ctx*> ctx(inflight, nullptr);
+  std::vector<g16_pkey*> key(inflight, nullptr);
+  for (int j = 0; j < inflight; ++j) {
+    if (ctx_create(0, &ctx[j]) != G16_OK) die("no usable GPU");
+    if (j == 0 || key_per_ctx) {
+      if (pkey_create(ctx[j], &d, &key[j]) != G16_OK) die(std::string("g16_pkey_create: ") + last_error(ctx[j]));
+    } else {
+      key[j] = key[0];
+    }
+  }
+  // fixed mask (Montgomery limbs of two arbitrary residues): the same proof from every build
+  uint8_t rmask[32], smask[32];
+  for (int i = 0; i < 32; ++i) rmask[i] = (uint8_t)(17 * i + 3), smask[i] = (uint8_t)(29 * i + 5);
+  rmask[31] = smask[31] = 0x10;
+  g16_proof ref;
+  if (prove(ctx[0], key[0], wf.values, G16_SCALARS_STD, rmask, smask, &ref) != G16_OK)
+    die(std::string("g16_prove: ") + last_error(ctx[0]));
+  std::atomic<int> bad{0};
+  auto batch = [&](int count) {
+    std::vector<std::thread> th;
+    for (int j = 0; j < inflight; ++j)
+      th.emplace_back([&, j]() {
+        g16_proof p;
+        for (int i = j; i < count; i += inflight) {
+          if (prove(ctx[j], key[j], wf.values, G16_SCALARS_STD, rmask, smask, &p) != G16_OK) ++bad;
+          else if (memcmp(&p, &ref, sizeof p)) ++bad;
+        }
+      });
+    for (auto& t : th) t.join();
+  };
+  batch(4 * inflight);   // warm-up: workspaces, clocks
+  // proof bytes as a short fingerprint, so that the A/B script can require identical proofs from every build
+  uint64_t fp = 1469598103934665603ull;
+  for (size_t i = 0; i < sizeof ref; ++i) fp = (fp ^ ((const uint8_t*)&ref)[i]) * 1099511628211ull;
+  for (int r = 0; r < reps; ++r) {
+    const double t0 = now();
+    batch(steps);
+    const double dt = now() - t0;
+    printf("%s proofs_per_s %.2f ms_per_proof %.3f steps %d inflight %d keys %d proof_fnv %016llx\n", lpath,
+           steps / dt, dt / steps * 1e3, steps, inflight, key_per_ctx ? inflight : 1, (unsigned long long)fp);
+    fflush(stdout);
+  }
+  // single-proof latency
+  {
+    const double t0 = now();
+    g16_proof p;
+    for (int i = 0; i < 5; ++i) prove(ctx[0], key[0], wf.values, G16_SCALARS_STD, rmask, smask, &p);
+    printf("%s latency_ms %.3f\n", lpath, (now() - t0) / 5 * 1e3);
+  }
+  if (bad) die("a proof failed or differed from the first one");
+  for (int j = 0; j < inflight; ++j)
+    if (j == 0 || key_per_ctx) pkey_destroy(key[j]);
+  for (int j = 0; j < inflight; ++j) ctx_destroy(ctx[j]);
+  return 0;
+}
