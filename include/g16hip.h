@@ -100,6 +100,10 @@ int32_t g16_points_register_g1_dev(g16_ctx* ctx, const void* d_points, size_t n,
 int32_t g16_points_register_g2_dev(g16_ctx* ctx, const void* d_points, size_t n, g16_points** out);
 void g16_points_release(g16_points* pts);
 size_t g16_points_count(const g16_points* pts);
+/* points at infinity (0,0) in the set (legal inputs: curves.nim:95-107; snarkjs keys hold one for every wire absent
+ * from a matrix).  A set with at least G16_INF_COMPACT percent of them (environment, default 10) gets bucket entry
+ * lists that leave them out, instead of paying a loop trip per (0,0) entry. */
+size_t g16_points_inf_count(const g16_points* pts);
 /* window size c and number of tables (= windows) chosen for this set; an MSM against it performs
  * count * ntables bucket additions + 2 * 2^(c-1) reduction additions */
 int32_t g16_points_info(const g16_points* pts, uint32_t* window_bits, uint32_t* ntables);
@@ -173,6 +177,10 @@ typedef struct { /* Proof (prover.nim:37-43) minus publicIO (= witness[0..npubs]
 } g16_proof;
 int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* desc, g16_pkey** out);
 void g16_pkey_destroy(g16_pkey* key);
+/* points at infinity per ProverPoints array of this key (this shard): out[0..4] = A1, B1, B2, C1, H1; out[5] = wires
+ * whose B1 AND B2 points are both (0,0); out[6] / out[7] = 1 if A1 / B1+B2 run on compacted entry lists (their own
+ * arrangement of the witness without those wires; sets below the G16_INF_COMPACT threshold share one arrangement). */
+int32_t g16_pkey_inf_counts(const g16_pkey* key, size_t out[8]);
 /* witness: nvars Fr values (flags: G16_SCALARS_MONT for Nim seq[Fr], G16_SCALARS_STD for raw .wtns,
  * | G16_SCALARS_DEVICE); mask_r / mask_s: Fr Montgomery (Mask, prover.nim:210-213), NULL = zero
  * (generateProofWithTrivialMask, prover.nim:308-310). */

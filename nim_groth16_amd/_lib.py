@@ -18,9 +18,9 @@ SYMBOLS = [
     "g16_selftest", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
     "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
-    "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_info", "g16_msm_points",
+    "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_inf_count", "g16_points_info", "g16_msm_points",
     "g16_points_check_g1", "g16_points_check_g2", "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
-    "g16_pkey_destroy", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
+    "g16_pkey_destroy", "g16_pkey_inf_counts", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
     "g16_prove_partials_begin", "g16_prove_partials_end",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
     "g16_vkey_create", "g16_vkey_destroy", "g16_verify", "g16_pairing",
@@ -97,6 +97,9 @@ def load_library():
     lib.g16_points_release.restype = None
     lib.g16_points_count.argtypes = [vp]
     lib.g16_points_count.restype = sz
+    lib.g16_points_inf_count.argtypes = [vp]
+    lib.g16_points_inf_count.restype = sz
+    lib.g16_pkey_inf_counts.argtypes = [vp, ctypes.POINTER(sz)]
     lib.g16_points_info.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     lib.g16_msm_points.argtypes = [vp, vp, vp, u32, vp]
     lib.g16_points_check_g1.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
@@ -126,6 +129,7 @@ def load_library():
     lib.g16_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
     for name in SYMBOLS:
         if name not in ("g16_ctx_destroy", "g16_last_error", "g16_points_release", "g16_points_count",
+                        "g16_points_inf_count",
                         "g16_pkey_destroy", "g16_vkey_destroy"):
             getattr(lib, name).restype = i32
     _lib = lib
@@ -361,6 +365,14 @@ class ProvingKey:
         raw = out.raw
         return raw[0:64], raw[64:192], raw[192:256]
 
+    def inf_counts(self) -> dict:
+        """points at infinity per ProverPoints array (this shard) and whether A1 / B1+B2 use compacted entry lists"""
+        out = (ctypes.c_size_t * 8)()
+        self.ctx._check(self.ctx._lib.g16_pkey_inf_counts(self._h, out))
+        v = list(out)
+        return {"A1": v[0], "B1": v[1], "B2": v[2], "C1": v[3], "H1": v[4], "B1_and_B2": v[5],
+                "compact_A": bool(v[6]), "compact_B": bool(v[7])}
+
     def build_abc(self, witness: bytes, mont: bool = True, ctx=None):
         c = ctx or self.ctx
         self._check_len(witness)
@@ -434,6 +446,10 @@ class PointSet:
     def __init__(self, ctx: Context, handle, group: int, n: int):
         self.ctx, self._h, self.group, self.n = ctx, handle, group, n
         ctx._children.add(self)
+
+    def inf_count(self) -> int:
+        """points at infinity (0,0) in the set"""
+        return self.ctx._lib.g16_points_inf_count(self._h)
 
     def info(self):
         """(window bits c, number of tables)"""

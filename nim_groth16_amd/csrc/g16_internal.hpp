@@ -23,6 +23,9 @@ struct G16Env {
   int g1_lanes[3] = {0, 2, 3};   // G16_G1_LANES  lanes of the A1 / B1 / C1 MSMs (three digits from {0,2,3})
   char stream_prio[7] = "lhllln";   // G16_STREAM_PRIO  six characters from {h, n, l}
   int red_slice_log2 = 0;  // G16_RED_SLICE    log2 of the chunks per reduce2 slice of a merged bucket set (8..11)
+  int inf_compact_pct = 10;   // G16_INF_COMPACT  point sets with at least this percentage of (0,0) points get their own
+                              // entry lists without them (0: always, 101: never); prover.hip
+  int r2_width = 1;        // G16_R2_WIDTH  0: reduce2 with 512 / 256-thread workgroups, 1: 128 / 64, 2: 64 / 64 (msm_stage.cuh)
   int ntt_tile = 2048;            // G16_NTT_TILE = 1024 | 2048 | 4096: NTT workgroup geometry (ntt.cuh)
   // launch order of a proof (experiments; the defaults are the measured optimum, tools/ab_schedule.sh):
   int quotient_first = 0;         // G16_QUOTIENT_FIRST=1: enqueue buildABC + quotient + sort(qs) before the witness MSMs
@@ -64,9 +67,9 @@ struct g16_ctx {
     hipEvent_t done = nullptr;
     Buf acc;
   };
-  MsmSort sort[2];
+  MsmSort sort[4];   // 0: witness (all pairs)  1: H scalars  2: witness, A1's live pairs  3: witness, B1/B2's live pairs
   MsmLane lane[5];
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_q = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_q = nullptr, ev_b2 = nullptr;
   Buf stage_s;   // staged scalars (host-pointer API)
   Buf stage_p;   // staged points
   Buf stage_p29; // the same points as reduced-radix entries (one-shot MSMs; registered sets keep their own tables)
@@ -187,13 +190,17 @@ struct ProfScope {
 // implemented in msm_g1.hip / msm_g2.hip / ntt.hip
 // table_c == 0: d_points = n affine points; table_c != 0: d_points = tables of a registered set
 int32_t g16_msm_device_g1(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
-                          void* d_out_aff, void* d_out_acc, uint32_t table_c);
+                          void* d_out_aff, void* d_out_acc, uint32_t table_c, const uint32_t* d_live = nullptr);
 int32_t g16_msm_device_g2(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
-                          void* d_out_aff, void* d_out_acc, uint32_t table_c);
+                          void* d_out_aff, void* d_out_acc, uint32_t table_c, const uint32_t* d_live = nullptr);
+// the live bitmap of a registered set if it holds enough (0,0) points for its own entry lists to pay (G16_INF_COMPACT)
+struct g16_points;
+const uint32_t* g16_points_live_if_sparse(const g16_points* p);
 // the two halves of an MSM: (1) arrange one scalar vector into buckets, (2) accumulate + reduce a point set
 // against that arrangement.  Several point sets may share one sort (same scalars, same n, same c).
+// d_live (optional): bitmap over the n pairs; pairs with a cleared bit get no entries (point sets with (0,0) points)
 int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, uint32_t flags, size_t n,
-                     uint32_t table_c, g16_ctx::MsmSort& sort);
+                     uint32_t table_c, g16_ctx::MsmSort& sort, const uint32_t* d_live = nullptr);
 int32_t g16_msm_reduce_g1(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
                           const void* d_points, void* d_out_aff, void* d_out_acc);
 int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
@@ -231,7 +238,14 @@ struct g16_points {
   size_t n = 0;
   uint32_t c = 0, nwin = 0;
   void* d_tables = nullptr;  // nwin * n affine points, table-major
+  uint32_t* d_live = nullptr;   // bitmap: bit i set <=> point i is not (0,0); ceil(n/32) words
+  size_t n_inf = 0;             // points at infinity in the set
 };
+// *d_n_inf (device u32, zeroed by the caller) += number of (0,0) points; bitmap: ceil(n/32) words
+int32_t g16_live_bitmap_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_bitmap, uint32_t* d_n_inf);
+int32_t g16_live_bitmap_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_bitmap, uint32_t* d_n_inf);
+int32_t g16_bitmap_or_device(g16_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n,
+                             uint32_t* d_n_dead);
 int32_t g16_sum_partials_device_g1(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
 int32_t g16_sum_partials_device_g2(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse);

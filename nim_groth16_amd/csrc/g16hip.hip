@@ -18,6 +18,8 @@ static G16Env read_env() {
   e.table_window = num("G16_TABLE_WINDOW", 5, 22);
   e.msm_seg = num("G16_MSM_SEG", 8, 4096);
   e.red_slice_log2 = num("G16_RED_SLICE", 8, 11);
+  if (const char* v = getenv("G16_INF_COMPACT")) e.inf_compact_pct = atoi(v) < 0 ? 0 : atoi(v) > 101 ? 101 : atoi(v);
+  if (const char* v = getenv("G16_R2_WIDTH")) e.r2_width = v[0] == '0' ? 0 : v[0] == '2' ? 2 : 1;
   if (const char* v = getenv("G16_LANES_AFTER_QUOTIENT")) e.lanes_after_quotient = v[0] != '0';
   if (const char* v = getenv("G16_QUOTIENT_FIRST")) e.quotient_first = v[0] != '0';
   if (const char* v = getenv("G16_NTT_TILE")) e.ntt_tile = atoi(v) == 1024 ? 1024 : atoi(v) == 4096 ? 4096 : 2048;
@@ -85,6 +87,7 @@ int32_t g16_lanes_init(g16_ctx* ctx) {
   if (hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   if (hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
+  if (hipEventCreateWithFlags(&ctx->ev_b2, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   return G16_OK;
 }
 
@@ -102,6 +105,7 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
   if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->ev_q) (void)hipEventDestroy(ctx->ev_q);
+  if (ctx->ev_b2) (void)hipEventDestroy(ctx->ev_b2);
   for (g16_ctx::Buf* b : {&ctx->stage_s, &ctx->stage_p, &ctx->stage_p29, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
                           &ctx->coset[0], &ctx->coset[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
                           &ctx->fb_table[1]})
@@ -268,8 +272,21 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
     if (!rc)
       rc = group == 1 ? g16_precompute_device_g1(ctx, d_src, n, h->c, h->d_tables)
                       : g16_precompute_device_g2(ctx, d_src, n, h->c, h->d_tables);
+    // which points are (0,0): snarkjs keys hold the point at infinity for every wire absent from a matrix
+    uint32_t n_inf = 0;
+    if (!rc && hipMalloc((void**)&h->d_live, ((n + 31) / 32 + 1) * 4) != hipSuccess) rc = G16_ENOMEM;
+    if (!rc) rc = ensure(ctx, ctx->stage_o, 2048);
+    if (!rc) {
+      uint32_t* d_cnt = (uint32_t*)ctx->stage_o.p;
+      if (hipMemsetAsync(d_cnt, 0, 4, ctx->stream) != hipSuccess) rc = G16_EHIP;
+      if (!rc) rc = group == 1 ? g16_live_bitmap_device_g1(ctx, d_src, n, h->d_live, d_cnt)
+                               : g16_live_bitmap_device_g2(ctx, d_src, n, h->d_live, d_cnt);
+      if (!rc && hipMemcpyAsync(&n_inf, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = G16_EHIP;
+    }
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = G16_EHIP;
+    h->n_inf = n_inf;
     if (rc) {
+      if (h->d_live) (void)hipFree(h->d_live);
       (void)hipFree(h->d_tables);
       delete h;
       if (ctx->err.empty()) ctx->err = "point registration failed";
@@ -299,8 +316,14 @@ extern "C" void g16_points_release(g16_points* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_tables);
+    if (h->d_live) (void)hipFree(h->d_live);
   }
   delete h;
+}
+extern "C" size_t g16_points_inf_count(const g16_points* h) { return h ? h->n_inf : 0; }
+const uint32_t* g16_points_live_if_sparse(const g16_points* p) {
+  return p && p->d_live && p->n && p->n_inf * 100 >= (size_t)g16_env().inf_compact_pct * p->n && p->n_inf ? p->d_live
+                                                                                                        : nullptr;
 }
 extern "C" size_t g16_points_count(const g16_points* h) { return h ? h->n : 0; }
 extern "C" int32_t g16_points_info(const g16_points* h, uint32_t* window_bits, uint32_t* ntables) {
@@ -400,8 +423,9 @@ extern "C" int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const voi
   if ((rc = ensure(ctx, ctx->stage_o, 512))) return rc;
   void* d_aff = partial ? nullptr : ctx->stage_o.p;
   void* d_acc = partial ? ctx->stage_o.p : nullptr;
-  rc = pts->group == 1 ? g16_msm_device_g1(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c)
-                       : g16_msm_device_g2(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c);
+  const uint32_t* live = g16_points_live_if_sparse(pts);
+  rc = pts->group == 1 ? g16_msm_device_g1(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c, live)
+                       : g16_msm_device_g2(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c, live);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_o.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

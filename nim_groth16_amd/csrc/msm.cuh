@@ -35,8 +35,13 @@ constexpr int FR_BITS = 254;
 // and is shifted right by c bits per window (8 funnel shifts with static register indices, c <= 22 < 32): no LDS
 // staging, no dynamic limb indexing, and any workgroup size.  (Rounds 1-2 staged the limbs in LDS and indexed them by
 // window: 36 KB of LDS per 1024 threads and two LDS reads per digit.)
+// `live` (optional): bitmap over the pairs; a cleared bit drops the pair before its scalar is even read -- the entry
+// lists of point sets with many points at infinity ((0,0) for every wire absent from a matrix, curves.nim:95-107)
+// then hold only the points that can contribute.
 template <class EMIT>
-__device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, uint32_t i, const MsmParams& P, EMIT&& emit) {
+__device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, const uint32_t* __restrict__ live, uint32_t i,
+                                           const MsmParams& P, EMIT&& emit) {
+  if (live && !((live[i >> 5] >> (i & 31)) & 1u)) return;
   u256 s = scalars[i];
   if (P.scalars_mont) s = Fr::from_mont(s);
   if (Fr::is_zero(s)) return;
@@ -54,24 +59,26 @@ __device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, uin
   }
 }
 
-static __global__ void __launch_bounds__(MSM_BLOCK) msm_count(const u256* __restrict__ scalars, MsmParams P,
-                                                       uint32_t* __restrict__ count) {
+static __global__ void __launch_bounds__(MSM_BLOCK) msm_count(const u256* __restrict__ scalars,
+                                                              const uint32_t* __restrict__ live, MsmParams P,
+                                                              uint32_t* __restrict__ count) {
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= P.n) return;
   const uint32_t bshift = P.c - 1;
-  msm_digits(scalars, i, P, [&](uint32_t w, uint32_t k, uint32_t) {
+  msm_digits(scalars, live, i, P, [&](uint32_t w, uint32_t k, uint32_t) {
     atomicAdd(&count[(P.tables ? 0u : (w << bshift)) + k], 1u);
   });
 }
 
-static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __restrict__ scalars, MsmParams P,
+static __global__ void __launch_bounds__(MSM_BLOCK) msm_scatter(const u256* __restrict__ scalars,
+                                                         const uint32_t* __restrict__ live, MsmParams P,
                                                          const uint32_t* __restrict__ offset,
                                                          uint32_t* __restrict__ cursor,
                                                          uint32_t* __restrict__ entries) {
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= P.n) return;
   const uint32_t bshift = P.c - 1;
-  msm_digits(scalars, i, P, [&](uint32_t w, uint32_t k, uint32_t neg) {
+  msm_digits(scalars, live, i, P, [&](uint32_t w, uint32_t k, uint32_t neg) {
     uint32_t b = (P.tables ? 0u : (w << bshift)) + k;
     uint32_t pos = offset[b] + atomicAdd(&cursor[b], 1u);
     // entry = point index (table-major when tables are used) | sign in bit 31
@@ -123,7 +130,8 @@ constexpr int PART_TILE = PART_BLOCK * PART_PER_THREAD;  // scalars per workgrou
 constexpr int PART_MAX = 8192;                           // max partitions (LDS histogram, 32 KB)
 
 template <bool SCATTER>
-static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __restrict__ scalars, MsmParams P,
+static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __restrict__ scalars,
+                                                               const uint32_t* __restrict__ live, MsmParams P,
                                                                uint32_t lo_bits, uint32_t nparts, uint32_t ntiles,
                                                                uint32_t* __restrict__ tile_hist,
                                                                uint2* __restrict__ tmp) {
@@ -136,7 +144,7 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
   for (uint32_t r = 0; r < PART_PER_THREAD; ++r) {
     uint32_t i = tile * PART_TILE + r * PART_BLOCK + threadIdx.x;
     if (i < P.n) {
-      msm_digits(scalars, i, P, [&](uint32_t w, uint32_t k, uint32_t neg) {
+      msm_digits(scalars, live, i, P, [&](uint32_t w, uint32_t k, uint32_t neg) {
         uint32_t part = (P.tables ? 0u : (w << hi_bits)) | (k >> lo_bits);
         uint32_t pos = lds_rank_add(hist, part);
         if (SCATTER) tmp[pos] = make_uint2((k & lo_mask) | (neg << 8), P.tables ? w * P.n + i : i);
@@ -793,6 +801,37 @@ __global__ void __launch_bounds__(256) points_on_curve(const typename C::Aff* __
   typename C::E lhs = F::sqr(p.y);
   typename C::E rhs = F::add(F::mul(F::sqr(p.x), p.x), b);
   if (!F::eq(lhs, rhs)) atomicMin(first_bad, i);
+}
+
+// ---- live bitmap of a point array: bit i set <=> point i is not the point at infinity (0,0) ------------------------
+// bitmap: ceil(n/32) words, zero-initialised is not required (every word is written); *n_inf += infinity points
+template <class C>
+__global__ void __launch_bounds__(256) points_live_bitmap(const typename C::Aff* __restrict__ pts, uint32_t n,
+                                                          uint32_t* __restrict__ bitmap, uint32_t* __restrict__ n_inf) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool livep = i < n && !C::is_inf(pts[i]);
+  const unsigned long long m = __ballot(livep);
+  const uint32_t lane = threadIdx.x & 63;
+  if (lane == 0 && i < n) {
+    bitmap[i >> 5] = (uint32_t)m;
+    if (i + 32 < n) bitmap[(i >> 5) + 1] = (uint32_t)(m >> 32);
+    const uint32_t valid = n - i < 64 ? n - i : 64;
+    const uint32_t dead = valid - (uint32_t)__popcll(m);
+    if (dead) atomicAdd(n_inf, dead);
+  }
+}
+// a |= b (word-wise); *n_dead += pairs that are dead in the union
+static __global__ void __launch_bounds__(256) bitmap_or(uint32_t* __restrict__ out, const uint32_t* __restrict__ a,
+                                                        const uint32_t* __restrict__ b, uint32_t n,
+                                                        uint32_t* __restrict__ n_dead) {
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= (n + 31) / 32) return;
+  uint32_t v = a[w] | b[w];
+  out[w] = v;
+  const uint32_t valid = n - 32 * w < 32 ? n - 32 * w : 32;
+  const uint32_t mask = valid == 32 ? 0xffffffffu : (1u << valid) - 1;
+  const uint32_t dead = valid - __popc(v & mask);
+  if (dead) atomicAdd(n_dead, dead);
 }
 
 // ---- fixed-base multiples of the group generator: out[i] = k_i * G  (fake_setup.nim:258-261 `y ** gen`) ----

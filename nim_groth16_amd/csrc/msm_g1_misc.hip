@@ -17,3 +17,18 @@ int32_t g16_on_curve_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uin
   const u256 b = Fp::add(Fp::dbl(Fp::one()), Fp::one());
   return on_curve_device<G1>(ctx, d_points, n, b, d_first_bad);
 }
+int32_t g16_live_bitmap_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_bitmap, uint32_t* d_n_inf) {
+  if (n)
+    KLAUNCH(ctx, "points_live_bitmap", points_live_bitmap<G1>, (uint32_t)((n + 255) / 256), 256, 0,
+            (const G1::Aff*)d_points, (uint32_t)n, d_bitmap, d_n_inf);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+int32_t g16_bitmap_or_device(g16_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n,
+                             uint32_t* d_n_dead) {
+  if (n)
+    KLAUNCH(ctx, "bitmap_or", bitmap_or, (uint32_t)(((n + 31) / 32 + 255) / 256), 256, 0, d_out, d_a, d_b, (uint32_t)n,
+            d_n_dead);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}

@@ -28,3 +28,10 @@ int32_t g16_on_curve_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uin
   b.c1 = std_fp(0x009713b0u, 0x3af0fed4u, 0xcd2cafadu, 0xeed8fdf4u, 0xa74fa084u, 0xe52d1852u, 0xe4a2bd06u, 0x85c315d2u);
   return on_curve_device<G2>(ctx, d_points, n, b, d_first_bad);
 }
+int32_t g16_live_bitmap_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_bitmap, uint32_t* d_n_inf) {
+  if (n)
+    KLAUNCH(ctx, "points_live_bitmap", points_live_bitmap<G2>, (uint32_t)((n + 255) / 256), 256, 0,
+            (const G2::Aff*)d_points, (uint32_t)n, d_bitmap, d_n_inf);
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}

@@ -62,7 +62,7 @@ static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
 
 // ---- phase 1: scalars -> bucket arrangement (count, scan, scatter, extra-segment list) ---------------------
 static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scalars, uint32_t flags, size_t n,
-                               uint32_t table_c, g16_ctx::MsmSort& S) {
+                               uint32_t table_c, g16_ctx::MsmSort& S, const uint32_t* d_live = nullptr) {
   const MsmParams P = msm_params(n, flags, table_c);
   S.P = P;
   size_t o = 0;
@@ -116,12 +116,12 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   const uint32_t ntiles = (P.nbuckets + SCAN_TILE - 1) / SCAN_TILE;
   if (use_part) {
     const uint32_t nt2 = (uint32_t)((nth + SCAN_TILE - 1) / SCAN_TILE);
-    KLAUNCH_ON(ctx, st, "msm_part_count", part_pass<false>, ptiles, PART_BLOCK, 0, scalars, P, lo_bits, nparts, ptiles,
+    KLAUNCH_ON(ctx, st, "msm_part_count", part_pass<false>, ptiles, PART_BLOCK, 0, scalars, d_live, P, lo_bits, nparts, ptiles,
                S.tile_hist, S.tmp);
     KLAUNCH_ON(ctx, st, "msm_scan", scan1_tile_sums, nt2, SCAN_BLOCK, 0, S.tile_hist, (uint32_t)nth, S.tiles2);
     KLAUNCH_ON(ctx, st, "msm_scan", scan_tiles, 1, SCAN_BLOCK, 0, S.tiles2, nt2, S.info + 8);  // total -> info[8]
     KLAUNCH_ON(ctx, st, "msm_scan", scan1_apply, nt2, SCAN_BLOCK, 0, S.tile_hist, (uint32_t)nth, S.tiles2);
-    KLAUNCH_ON(ctx, st, "msm_part_scatter", part_pass<true>, ptiles, PART_BLOCK, 0, scalars, P, lo_bits, nparts,
+    KLAUNCH_ON(ctx, st, "msm_part_scatter", part_pass<true>, ptiles, PART_BLOCK, 0, scalars, d_live, P, lo_bits, nparts,
                ptiles, S.tile_hist, S.tmp);
     KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_hist, nparts * BS_SPLIT, 256, 0, S.tmp, S.tile_hist, ptiles, nparts,
                S.info + 8, S.slice_hist);
@@ -129,7 +129,7 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
                S.info + 8, S.slice_hist, P, lo_bits, S.count, S.offset, S.entries, fused ? 1u : 0u, S.xoff, S.heavy,
                S.info, S.ghist, S.blk_base);
   } else {
-    KLAUNCH_ON(ctx, st, "msm_count", msm_count, nblk, MSM_BLOCK, 0, scalars, P, S.count);
+    KLAUNCH_ON(ctx, st, "msm_count", msm_count, nblk, MSM_BLOCK, 0, scalars, d_live, P, S.count);
   }
   const uint32_t pblk = (P.nbuckets + PERM_BLOCK - 1) / PERM_BLOCK;
   if (!fused) {
@@ -142,7 +142,7 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   KLAUNCH_ON(ctx, st, "msm_perm", perm_scatter, pblk, PERM_BLOCK, 0, S.count, P.nbuckets, S.ghist, S.blk_base,
              S.perm);
   if (!use_part)
-    KLAUNCH_ON(ctx, st, "msm_scatter", msm_scatter, nblk, MSM_BLOCK, 0, scalars, P, S.offset, S.cursor, S.entries);
+    KLAUNCH_ON(ctx, st, "msm_scatter", msm_scatter, nblk, MSM_BLOCK, 0, scalars, d_live, P, S.offset, S.cursor, S.entries);
   KLAUNCH_ON(ctx, st, "msm_make_extra", msm_make_extra, 512, MSM_BLOCK, 0, S.heavy, S.info, S.offset, S.xoff, P.seg,
              P.max_extra, S.xseg);
   HIPCHK(ctx, hipGetLastError());

@@ -5,8 +5,8 @@
 uint32_t g16_pick_window_g1(size_t n) { return pick_table_window(n); }
 
 int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, uint32_t flags, size_t n, uint32_t table_c,
-                     g16_ctx::MsmSort& sort) {
-  return msm_sort_device(ctx, stream, d_scalars, flags, n, table_c, sort);
+                     g16_ctx::MsmSort& sort, const uint32_t* d_live) {
+  return msm_sort_device(ctx, stream, d_scalars, flags, n, table_c, sort, d_live);
 }
 
 // phase 2: accumulate + reduce one point set against a bucket arrangement; d_out_aff / d_out_acc: device
@@ -50,8 +50,8 @@ int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, c
 }
 // one complete MSM on the context's main stream
 static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
-                          void* d_out_aff, void* d_out_acc, uint32_t table_c) {
-  int32_t rc = msm_sort_device(ctx, ctx->stream, d_scalars, flags, n, table_c, ctx->sort[0]);
+                          void* d_out_aff, void* d_out_acc, uint32_t table_c, const uint32_t* d_live) {
+  int32_t rc = msm_sort_device(ctx, ctx->stream, d_scalars, flags, n, table_c, ctx->sort[0], d_live);
   if (rc) return rc;
   if (table_c == 0 && n) {   // plain point array: the accumulate kernel reads reduced-radix entries
     const size_t esz = group == 1 ? 64 : 128;
@@ -64,10 +64,10 @@ static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32
   return msm_reduce(ctx, ctx->stream, ctx->lane[0].acc, ctx->sort[0], group, d_points, d_out_aff, d_out_acc);
 }
 int32_t g16_msm_device_g1(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* aff, void* acc,
-                          uint32_t table_c) {
-  return msm_device(ctx, 1, s, f, p, n, aff, acc, table_c);
+                          uint32_t table_c, const uint32_t* d_live) {
+  return msm_device(ctx, 1, s, f, p, n, aff, acc, table_c, d_live);
 }
 int32_t g16_msm_device_g2(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* aff, void* acc,
-                          uint32_t table_c) {
-  return msm_device(ctx, 2, s, f, p, n, aff, acc, table_c);
+                          uint32_t table_c, const uint32_t* d_live) {
+  return msm_device(ctx, 2, s, f, p, n, aff, acc, table_c, d_live);
 }

@@ -72,10 +72,29 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::M
     for (uint32_t ks = cps * RED_CHUNK; ks > 1; ks >>= 1) ++log2ks;
   }
   auto* wtot = wsum + 65;
-  constexpr int R2B = sizeof(typename C::Aff) == 64 ? 512 : 256;   // as wide as the register budget allows
-  KLAUNCH_ON(ctx, st, g2 ? "msm_reduce2_g2" : "msm_reduce2_g1", (msm_reduce2<C, R2B>), nsets, R2B,
-             R2B * sizeof(typename C::Acc), (const typename C::Acc*)chunkR, (const typename C::Acc*)chunkA,
-             (uint32_t)(nchunks / nsets), wsum, wtot);
+  // Workgroup width of reduce2.  The kernel is a latency chain (serial chunk sums -> Hillis-Steele suffix scan ->
+  // tree), and every scan step costs one group addition on EVERY wave of the workgroup.  Wide workgroups (512 / 256
+  // threads: one chunk per thread) have the shortest chain; narrow ones (128 / 64 threads: four chunks per thread,
+  // work-efficient serial sums, a 7- / 6-step scan) issue ~2.5x fewer wave-instructions for a ~20 % longer chain.
+  // A proof's throughput is bound by instruction issue over ALL its kernels (same-box A/B, profiles/r03_ab_knobs.txt:
+  // 111.6 -> 114.7 proofs/s, single-proof latency 11.67 -> 11.85 ms), so narrow is the default;
+  // G16_R2_WIDTH=0 selects the wide geometry (lowest single-MSM latency), 2 a single wave per slice.
+  constexpr int R2B = sizeof(typename C::Aff) == 64 ? 512 : 256;
+  constexpr int R2N = R2B / 4;
+  const auto* cR = (const typename C::Acc*)chunkR;
+  const auto* cA = (const typename C::Acc*)chunkA;
+  const uint32_t cps = (uint32_t)(nchunks / nsets);
+  const char* nm = g2 ? "msm_reduce2_g2" : "msm_reduce2_g1";
+  switch (g16_env().r2_width) {
+    case 0:
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), nsets, R2B, R2B * sizeof(typename C::Acc), cR, cA, cps, wsum, wtot);
+      break;
+    case 2:
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, 64>), nsets, 64, 64 * sizeof(typename C::Acc), cR, cA, cps, wsum, wtot);
+      break;
+    default:
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), nsets, R2N, R2N * sizeof(typename C::Acc), cR, cA, cps, wsum, wtot);
+  }
   if (P.tables)
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, 1, 128, 0, wsum, wtot, nsets, log2ks,
                (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);

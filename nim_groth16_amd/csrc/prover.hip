@@ -33,6 +33,14 @@ struct g16_pkey {
   size_t ncoeffs = 0;
   g1_aff alpha1, beta1, delta1;
   g2_aff beta2, delta2;
+  // Points at infinity.  snarkjs keys hold (0,0) in pointsA1 / pointsB1 / pointsB2 for every wire absent from the
+  // matrix (the loaders accept them, curves.nim:95-107; the MSMs sum over them, msm.nim:128-158).  In the shared
+  // witness sort such an entry still occupies a loop trip of a wave whose other lanes run a full addition, so a set
+  // with >= G16_INF_COMPACT % of them gets entry lists of its own that leave them out: liveA = A1's bitmap, liveB =
+  // the union of B1's and B2's (one sort serves both).  nullptr = dense: the set rides on the shared sort.
+  const uint32_t* liveA = nullptr;
+  uint32_t* liveB = nullptr;      // owned (the union), or nullptr
+  size_t deadB = 0;               // wires whose B1 AND B2 points are both (0,0)
 };
 
 // ---- buildABC ---------------------------------------------------------------------------------------
@@ -111,7 +119,19 @@ extern "C" void g16_pkey_destroy(g16_pkey* k) {
   if (k->d_rowptr) (void)hipFree(k->d_rowptr);
   if (k->d_col) (void)hipFree(k->d_col);
   if (k->d_val) (void)hipFree(k->d_val);
+  if (k->liveB) (void)hipFree(k->liveB);
   delete k;
+}
+
+// points at infinity per set: out[0..4] = A1, B1, B2, C1 (without the public wires this library pads it with), H1;
+// out[5] = wires whose B1 and B2 points are both (0,0); out[6] = 1 if A1, out[7] = 1 if B1/B2 use compacted entry lists
+extern "C" int32_t g16_pkey_inf_counts(const g16_pkey* k, size_t out[8]) {
+  if (!k || !out) return G16_EINVAL;
+  size_t pad = 0;
+  for (size_t wI = k->w_lo; wI < k->w_hi; ++wI) pad += wI <= k->npubs ? 1 : 0;
+  out[0] = k->A1->n_inf, out[1] = k->B1->n_inf, out[2] = k->B2->n_inf, out[3] = k->C1->n_inf - pad, out[4] = k->H1->n_inf;
+  out[5] = k->deadB, out[6] = k->liveA ? 1 : 0, out[7] = k->liveB ? 1 : 0;
+  return G16_OK;
 }
 
 extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pkey** out) {
@@ -173,6 +193,27 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
   TRY(g16_points_register_g2(ctx, (const char*)d->pointsB2 + 128 * k->w_lo, k->w_hi - k->w_lo, &k->B2));
   TRY(g16_points_register_g1(ctx, c1pad.data(), k->w_hi - k->w_lo, &k->C1));
   TRY(g16_points_register_g1(ctx, (const char*)d->pointsH1 + 64 * k->h_lo, k->h_hi - k->h_lo, &k->H1));
+  {   // sparse sets get their own entry lists (see g16_pkey)
+    const size_t nw = k->w_hi - k->w_lo;
+    k->liveA = g16_points_live_if_sparse(k->A1);
+    if (nw && k->B1->d_live && k->B2->d_live) {
+      uint32_t* d_cnt = nullptr;
+      uint32_t dead = 0;
+      TRY(ensure(ctx, ctx->stage_o, 2048));
+      d_cnt = (uint32_t*)ctx->stage_o.p;
+      if (hipMalloc((void**)&k->liveB, ((nw + 31) / 32 + 1) * 4) != hipSuccess) TRY(G16_ENOMEM);
+      if (hipMemsetAsync(d_cnt, 0, 4, ctx->stream) != hipSuccess) TRY(G16_EHIP);
+      TRY(g16_bitmap_or_device(ctx, k->liveB, k->B1->d_live, k->B2->d_live, nw, d_cnt));
+      if (hipMemcpyAsync(&dead, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        TRY(G16_EHIP);
+      k->deadB = dead;
+      if (!dead || dead * 100 < (size_t)g16_env().inf_compact_pct * nw) {   // dense: share the witness sort
+        (void)hipFree(k->liveB);
+        k->liveB = nullptr;
+      }
+    }
+  }
   // CSR by counting sort on (matrix, row): A entries first, then B (sum order is irrelevant mod r)
   const g16_coeff* cf = (const g16_coeff*)d->coeffs;
   std::vector<uint32_t> rowptr(2 * (n + 1), 0);
@@ -312,20 +353,35 @@ static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, uint32_t fla
   const size_t nw = k->w_hi - k->w_lo;
   if (nw) {
     g16_ctx::MsmLane* L = ctx->lane;
-    HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
-    if ((rc = g16_msm_sort(ctx, L[0].stream, b.d_w + k->w_lo, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
-    for (int i = 0; i < 4; ++i) {
-      if (i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, ctx->ev_b, 0));
-      if (after) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, after, 0));
-    }
-    if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, ctx->sort[0], k->B2->d_tables, nullptr, b.slots + PART_B2)))
-      return rc;
     // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES (read once per process, g16_env) reassigns them
     const int la = g16_env().g1_lanes[0], lb = g16_env().g1_lanes[1], lc = g16_env().g1_lanes[2];
-    if ((rc = g16_msm_reduce_g1(ctx, L[la].stream, L[la].acc, ctx->sort[0], k->A1->d_tables, nullptr, b.slots + PART_A)))
+    const u256* d_wr = b.d_w + k->w_lo;
+    HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
+    if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
+    for (int i = 1; i < 4; ++i)   // (lane 1 sorts for itself when B is sparse: it needs the witness, not lane 0's sort)
+      HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, i == 1 && k->liveB ? ctx->ev_a : ctx->ev_b, 0));
+    if (after)
+      for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, after, 0));
+    // B1 / B2 with many (0,0) points: their own arrangement of the witness (live pairs only), built on B2's lane
+    // while lane 0 arranges the full witness
+    const g16_ctx::MsmSort* sortB = &ctx->sort[0];
+    if (k->liveB) {
+      if ((rc = g16_msm_sort(ctx, L[1].stream, d_wr, wflags, nw, k->B2->c, ctx->sort[3], k->liveB))) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev_b2, L[1].stream));
+      HIPCHK(ctx, hipStreamWaitEvent(L[lb].stream, ctx->ev_b2, 0));
+      sortB = &ctx->sort[3];
+    }
+    if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, *sortB, k->B2->d_tables, nullptr, b.slots + PART_B2)))
       return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[lb].stream, L[lb].acc, ctx->sort[0], k->B1->d_tables, nullptr, b.slots + PART_B1)))
+    const g16_ctx::MsmSort* sortA = &ctx->sort[0];
+    if (k->liveA) {   // likewise A1, on its own lane
+      if ((rc = g16_msm_sort(ctx, L[la].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[2], k->liveA))) return rc;
+      sortA = &ctx->sort[2];
+    }
+    if ((rc = g16_msm_reduce_g1(ctx, L[la].stream, L[la].acc, *sortA, k->A1->d_tables, nullptr, b.slots + PART_A)))
+      return rc;
+    if ((rc = g16_msm_reduce_g1(ctx, L[lb].stream, L[lb].acc, *sortB, k->B1->d_tables, nullptr, b.slots + PART_B1)))
       return rc;
     if ((rc = g16_msm_reduce_g1(ctx, L[lc].stream, L[lc].acc, ctx->sort[0], k->C1->d_tables, nullptr, b.slots + PART_C)))
       return rc;

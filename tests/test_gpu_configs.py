@@ -137,16 +137,18 @@ def _prove_mixed(ctx, orc, log2n, **kw):
         std = generateProofWithMask(0, False, zk, Witness("bn128", m + 2, I.fr_std_bytes(wit), std=True), mask, ctx,
                                     pkey=pk)
         assert (std.pi_a, std.pi_b, std.pi_c) == (pr.pi_a, pr.pi_b, pr.pi_c)
+        inf = pk.inf_counts()
     finally:
         pk.destroy()
-    return zk, wit
+    return zk, wit, inf
 
 
 def test_full_proof_2p18_circom_like_witness_bit_exact(ctx, orc):
     """a 2^18-constraint circuit whose witness is 40 % zeros and 30 % ones (booleanity rows b*b = b next to the
     squaring chain): the four witness MSMs share one sort in which a single bucket holds ~30 % of all entries
     (msm_accum extra segments -> msm_heavy).  Bit-exact vs the C oracle, both witness encodings."""
-    zk, wit = _prove_mixed(ctx, orc, 18)
+    zk, wit, inf = _prove_mixed(ctx, orc, 18)
+    assert not inf["compact_A"] and not inf["compact_B"]       # every wire occurs in A and in B: dense sets, ONE sort
     nz = sum(1 for w in wit if w == 0) / len(wit)
     no = sum(1 for w in wit if w == 1) / len(wit)
     assert nz + no >= 0.6 and nz > 0.35 and no > 0.25
@@ -156,13 +158,37 @@ def test_full_proof_2p18_circom_like_witness_bit_exact(ctx, orc):
 def test_full_proof_with_infinity_points_in_B(ctx, orc, lin_pct, log2n):
     """snarkjs keys carry (0,0) for every wire absent from B (curves.nim:95-107 accepts them, msm.nim:128-158 sums
     over them): here 50 % / 90 % of pointsB1 and pointsB2 are the point at infinity.  Bit-exact vs the C oracle."""
-    zk, _ = _prove_mixed(ctx, orc, log2n, zero_pct=0, one_pct=0, lin_pct=lin_pct)
+    zk, _, inf = _prove_mixed(ctx, orc, log2n, zero_pct=0, one_pct=0, lin_pct=lin_pct)
     b2 = zk.pPoints.pointsB2
     ninf = sum(1 for i in range(0, len(b2), 128) if b2[i:i + 128] == bytes(128))
     b1 = zk.pPoints.pointsB1
     assert ninf == sum(1 for i in range(0, len(b1), 64) if b1[i:i + 64] == bytes(64))
     frac = ninf / zk.header.nvars
     assert abs(frac - lin_pct / 100) < 0.08, frac
+    # the library saw the same points, and gave B1 / B2 their own entry lists without them (g16_pkey_inf_counts)
+    assert inf["B1"] == inf["B2"] == inf["B1_and_B2"] == ninf and inf["compact_B"] and not inf["compact_A"]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_registered_msm_with_mostly_infinity_points(ctx, orc, group):
+    """a registered set with 60 % (0,0) points runs on compacted entry lists (g16_points_inf_count); result == the
+    oracle's MSM over the same arrays, which adds the infinities the long way (msm.nim:162-198 semantics)"""
+    n = 1 << 13
+    ks, sc = _stream(1, n), _stream(2, n)
+    psz = 64 * group
+    pts = bytearray(ctx.fixed_base(group, _bytes(ks)))
+    dead = [i for i in range(n) if (i * 2654435761) % 100 < 60]
+    for i in dead:
+        pts[psz * i: psz * (i + 1)] = bytes(psz)
+    pts = bytes(pts)
+    h = ctx.register_points(group, pts, n)
+    try:
+        assert h.inf_count() == len(dead)
+        got = ctx.msm_points(h, _bytes(sc))
+    finally:
+        h.release()
+    assert got == orc.msm(group, _bytes(sc), pts)
+    assert got == ctx.msm(group, _bytes(sc), pts, n)
 
 
 # ---- full-size NTT and quotient against every output of the C oracle ----------------------------------------------

@@ -2,7 +2,8 @@
 # Paired same-box A/B of several builds of libg16hip.so: ONE session, ONE key file, ONE binary
 # (tools/ab_prove.cpp dlopen()s each build), the builds ALTERNATING for `alts` rounds so that clock / thermal drift of
 # the box hits all of them alike.  Prints every batch and, at the end, median / min / max proofs/s per build.
-#   bash tools/ab_rounds.sh <alts> <out.txt> name=path[:K] ...      (":K" = one key per context: round 1's rule)
+#   bash tools/ab_rounds.sh <alts> <out.txt> name=path[:K][@VAR=val,VAR=val] ...
+#   ":K" = one key per context (round 1's rule); "@..." = G16_* knobs for that entry (same library, other settings)
 # e.g. bash tools/ab_rounds.sh 5 gpurun_out/ab.txt r01=nim_groth16_amd/csrc/build_variants/libg16hip_r01.so:K \
 #        r02=nim_groth16_amd/csrc/build_variants/libg16hip_r02.so r03=nim_groth16_amd/csrc/libg16hip.so
 set -e
@@ -14,9 +15,10 @@ g++ -O2 -std=c++17 -Iinclude tools/ab_prove.cpp -ldl -lpthread -o "$dir/ab_prove
 : > "$out"
 for rep in $(seq 1 "$alts"); do
   for spec in "$@"; do
-    name=${spec%%=*}; path=${spec#*=}; kflag=""
+    name=${spec%%=*}; path=${spec#*=}; kflag=""; envs=""
+    case "$path" in *@*) envs=$(echo "${path#*@}" | tr ',' ' '); path=${path%%@*};; esac
     case "$path" in *:K) path=${path%:K}; kflag="-K";; esac
-    "$dir/ab_prove" -l "$PWD/$path" -z "$dir/c.zkey" -w "$dir/c.wtns" -k ${AB_STEPS:-96} -r 2 $kflag 2>/dev/null \
+    env $envs "$dir/ab_prove" -l "$PWD/$path" -z "$dir/c.zkey" -w "$dir/c.wtns" -k ${AB_STEPS:-96} -r 2 $kflag 2>/dev/null \
       | sed "s|^$PWD/$path|$name|" | tee -a "$out"
   done
 done
