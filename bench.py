@@ -86,6 +86,50 @@ def self_launch(args, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def lib_sha16():
+    """identity of the library build the static roofline inputs must belong to"""
+    import hashlib
+    from nim_groth16_amd._lib import lib_path
+    h = hashlib.sha256()
+    with open(lib_path(), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def build_inputs(args, ctx, rank, world, dist):
+    """The circuit, its key and NWITNESS satisfying witnesses.  Rank 0 alone runs the ~25 s of Python big-integer
+    setup (and the fixed-base multiplications on its GPU); the other ranks of a multi-GPU launch load what it wrote
+    (one pickle in /dev/shm) instead of repeating it."""
+    import pickle
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import SplitMix64, squaringChain
+    n = 1 << args.log2n
+    m = n - 2
+    path = f"/dev/shm/g16bench_{os.environ.get('MASTER_PORT', '0')}_{args.log2n}.pkl"
+    if rank == 0:
+        r1cs, wit0 = squaringChain(m, seed=4)
+        # more satisfying witnesses of the SAME circuit: the chain constants k_i (which are what the key depends on)
+        # stay, the free input w_0 changes, and with it every wire
+        wits = [wit0] + [squaringChain(m, seed=4, w0=w0)[1] for w0 in (5, 7, 11, 13)[:NWITNESS - 1]]
+        rng = SplitMix64(5)
+        tox = ToxicWaste(*[rng.fr() for _ in range(5)])
+        zkey = fakeCircuitSetup(r1cs, tox, 1, ctx)           # scalar side on the host, every `y ** gen` on the GPU
+        if world > 1:
+            with open(path + ".tmp", "wb") as f:
+                pickle.dump((zkey, wits), f, protocol=pickle.HIGHEST_PROTOCOL)
+            os.replace(path + ".tmp", path)
+    if world > 1:
+        dist.barrier()
+        if rank != 0:
+            with open(path, "rb") as f:
+                zkey, wits = pickle.load(f)
+        dist.barrier()
+        if rank == 0:
+            os.remove(path)
+    return zkey, wits
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -116,23 +160,43 @@ def main(argv=None):
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    # Everything between the rendezvous and its teardown runs under one guard: a failure on ANY rank (a worker
+    # error, a library error) is shared through an all-reduced flag before the next collective, so that every rank
+    # leaves with a non-zero code instead of waiting in a barrier for a rank that is gone.
+    state = {}
+    err = None
+    try:
+        measure(args, rank, world, local, dist, coll_dev, state)
+    except BaseException as e:       # noqa: BLE001 -- re-raised below, after the other ranks have been told
+        err = e
+    if dist is not None:
+        try:
+            flag = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if err is None and flag.item() > 0:
+                err = SystemExit("FAIL: another rank failed")
+        finally:
+            dist.destroy_process_group()
+    if err is not None:
+        raise err if isinstance(err, SystemExit) else SystemExit(f"FAIL: {err!r}")
+    # The oracle gate and the CPU baseline run AFTER the process group is gone: 3 x ~14 s of CPU work on rank 0
+    # during which no other rank idles inside a collective.
+    if rank == 0:
+        finish_rank0(args, world, state)
+
+
+def measure(args, rank, world, local, dist, coll_dev, state):
+    import threading
+    import torch
     from nim_groth16_amd import Context, Mask, loadProvingKey
     from nim_groth16_amd import bn128 as F
-    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
-    from nim_groth16_amd.synthetic import SplitMix64, squaringChain
+    from nim_groth16_amd.synthetic import SplitMix64
 
     ctx = Context(local)
     ctx.selftest()
     n = 1 << args.log2n
-    m = n - 2
     t0 = time.time()
-    r1cs, wit0 = squaringChain(m, seed=4)
-    # more satisfying witnesses of the SAME circuit: the chain constants k_i (which are what the key depends on) stay,
-    # the free input w_0 changes, and with it every wire
-    wits = [wit0] + [squaringChain(m, seed=4, w0=w0)[1] for w0 in (5, 7, 11, 13)[:NWITNESS - 1]]
-    rng = SplitMix64(5)
-    tox = ToxicWaste(*[rng.fr() for _ in range(5)])
-    zkey = fakeCircuitSetup(r1cs, tox, 1, ctx)           # scalar side on the host, every `y ** gen` on the GPU
+    zkey, wits = build_inputs(args, ctx, rank, world, dist)
     mrng = SplitMix64(6)
     mask = Mask(mrng.fr(), mrng.fr())
     log(f"[bench] setup (synthetic circuit, {NWITNESS} witnesses, fake trusted setup, domain 2^{args.log2n}): "
@@ -152,36 +216,9 @@ def main(argv=None):
     torch.cuda.synchronize()
     log(f"[bench] key upload + window tables: {time.time()-t0:.1f}s")
 
-    inflight = 1 if shard else max(1, args.inflight)
-    ctxs = [ctx] + [Context(local) for _ in range(inflight - 1)]      # ONE key, `inflight` contexts
-    torch.cuda.synchronize()
-
-    if shard:
-        # one proof over all ranks (nim_groth16_amd/distributed.py): sharded MSMs, the three coset pipelines of the
-        # quotient on three different ranks (--quotient tasks) or replicated on all of them (--quotient replicated),
-        # then one all-gather of the 768-byte partial records
-        from nim_groth16_amd.distributed import ShardedProver
-        sp = ShardedProver(zkey, rank, world, ctx=ctx, quotient=args.quotient, pkey=pkey)
-
-        def step(i, lane=0, hbm=False):
-            w = (d_w if hbm else h_w)[i % NWITNESS]
-            return sp.prove_raw(w.data_ptr(), False, rb, sb, device=hbm)
-    else:
-        def step(i, lane=0, hbm=False):
-            w = (d_w if hbm else h_w)[i % NWITNESS]
-            return pkey.prove(w.data_ptr(), mont=False, r=rb, s=sb, device=hbm, ctx=ctxs[lane])
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        for c in ctxs:
-            c.synchronize()
-
-    import threading
+    inflight = max(1, args.inflight)
     proofs = [None] * NWITNESS         # last proof seen per witness
     plock = threading.Lock()
-
     errors = []                        # worker threads cannot end the process: failures are collected and re-raised
 
     def keep(i, p):
@@ -191,36 +228,78 @@ def main(argv=None):
                 errors.append(f"two proofs of witness {k} differ (step {i})")
             proofs[k] = p
 
-    def run(count, hbm=False):
-        """`count` proofs, `inflight` at a time: worker j proves steps j, j+inflight, ... on its own context"""
-        if inflight == 1:
+    if shard:
+        # one proof over all ranks (nim_groth16_amd/distributed.py): sharded MSMs, the three coset pipelines of the
+        # quotient on three different ranks (--quotient tasks) or replicated on all of them (--quotient replicated),
+        # one all-gather of the 768-byte partial records; `--inflight` sharded proofs overlap (a context each)
+        from nim_groth16_amd.distributed import ShardedProver
+        inflight = min(inflight, 2) if args.inflight == 3 else inflight      # default depth of the shard pipeline: 2
+        sp = ShardedProver(zkey, rank, world, ctx=ctx, quotient=args.quotient, pkey=pkey, depth=inflight)
+        ctxs = [ctx]
+
+        def step(i, lane=0, hbm=False):
+            w = (d_w if hbm else h_w)[i % NWITNESS]
+            return sp.prove_raw(w.data_ptr(), False, rb, sb, device=hbm)
+
+        def run(count, hbm=False):
+            """`count` sharded proofs through the pipeline (submit / collect, `inflight` in flight)"""
+            done = 0
             for i in range(count):
-                keep(i, step(i, 0, hbm))
+                w = (d_w if hbm else h_w)[i % NWITNESS]
+                p = sp.submit(w.data_ptr(), False, rb, sb, device=hbm)
+                if p is not None:
+                    keep(done, p)
+                    done += 1
+            for p in sp.collect():
+                keep(done, p)
+                done += 1
             if errors:
                 raise SystemExit("FAIL: " + "; ".join(errors))
-            return
+    else:
+        ctxs = [ctx] + [Context(local) for _ in range(inflight - 1)]      # ONE key, `inflight` contexts
 
-        def work(j):
-            try:
-                torch.cuda.set_device(local)     # a new host thread starts on device 0 (the library sets it per call too)
-                for i in range(j, count, inflight):
-                    keep(i, step(i, j, hbm))
-            except BaseException as e:      # a G16Error in a worker must fail the run, not just end the thread
-                with plock:
-                    errors.append(f"worker {j}: {e!r}")
-        th = [threading.Thread(target=work, args=(j,)) for j in range(inflight)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errors:
-            raise SystemExit("FAIL: " + "; ".join(errors))
+        def step(i, lane=0, hbm=False):
+            w = (d_w if hbm else h_w)[i % NWITNESS]
+            return pkey.prove(w.data_ptr(), mont=False, r=rb, s=sb, device=hbm, ctx=ctxs[lane])
+
+        def run(count, hbm=False):
+            """`count` proofs, `inflight` at a time: worker j proves steps j, j+inflight, ... on its own context"""
+            def work(j):
+                try:
+                    torch.cuda.set_device(local)   # a new host thread starts on device 0 (the library sets it per call too)
+                    for i in range(j, count, inflight):
+                        keep(i, step(i, j, hbm))
+                except BaseException as e:      # a G16Error in a worker must fail the run, not just end the thread
+                    with plock:
+                        errors.append(f"worker {j}: {e!r}")
+            th = [threading.Thread(target=work, args=(j,)) for j in range(inflight)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errors:
+                raise SystemExit("FAIL: " + "; ".join(errors))
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.synchronize()
+
+    def allmax(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     run(max(args.warmup, inflight, NWITNESS), hbm=args.witness == "hbm")
     barrier()
-    # HIP-event timing of the dominant kernels (bucket accumulation) runs INSIDE the timed region, on this rank's
-    # first context; events are recorded on the stream each kernel is launched on.  (Events around all ~120 launches
-    # of a proof cost ~3 % of throughput, so the full per-kernel breakdown is taken on extra steps afterwards.)
+    # HIP events around the bucket-accumulation kernels run INSIDE the timed region, on this rank's first context
+    # (recorded on the stream each kernel is launched on): the CONTENDED duration of the dominant kernel, reported
+    # next to the uncontended one below.  (Events around all ~110 launches of a proof would cost ~3 % of throughput.)
     ctx.profile(2 if rank == 0 else 0)
     ctx.profile_reset()
     t0 = time.perf_counter()
@@ -229,13 +308,6 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     rep = ctx.profile_report() if rank == 0 else {}
     ctx.profile(False)
-
-    def allmax(x):
-        if dist is None:
-            return x
-        tt = torch.tensor([x], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
     dt = allmax(dt)
     proofs_done = args.steps * (1 if shard or world == 1 else world)
     value = proofs_done / dt
@@ -248,130 +320,157 @@ def main(argv=None):
     dt2 = allmax(time.perf_counter() - t1)
     value_other = k2 * (1 if shard or world == 1 else world) / dt2
     # single-proof latency (one proof in flight, host witness), reported next to the throughput
+    barrier()
     t1 = time.perf_counter()
     for i in range(3):
         step(i)
     lat_ms = (time.perf_counter() - t1) / 3 * 1e3
+    barrier()
+    if shard:
+        sp.close()
 
-    # ---- roofline of the dominant kernel of the step (from the events of the timed region) -------------------
-    roof, extra = None, {}
-    reps = 3
-    if rank == 0 or shard:            # in shard mode a step contains a collective: every rank must take part
-        ctx.profile(1 if rank == 0 else 0)
-        ctx.profile_reset()
-        for i in range(reps):
-            step(i)
-        rep_all = ctx.profile_report() if rank == 0 else {}
-        ctx.profile(False)
-    if rank == 0:
-        kern = {k: v["total_ms"] / v["calls"] for k, v in rep.items()}
-        kern_all = {k: v["total_ms"] / v["calls"] for k, v in rep_all.items()}
-        calls = {k: v["calls"] // reps for k, v in rep_all.items()}
-        dom = max(rep, key=lambda k: rep[k]["total_ms"])
-        nsh = (n // world) if shard else n
-        # algorithmic bytes of one launch: a G1 MSM reads 32+64 B per pair, a G2 MSM 32+128 B
-        per_pair = {"g1": 96, "g2": 160}
-        alg = per_pair["g2" if dom.endswith("g2") else "g1"] * nsh if dom.startswith("msm_") else 64 * n
-        achieved = alg / (kern[dom] * 1e-3) / 1e9
-        # measured HBM bytes per launch of that kernel (rocprofv3 PMC passes; see profiles/README.md)
-        traffic = None
-        try:
-            if args.log2n == 20 and not shard:
-                for name in ("r02_pmc_hbm_traffic_2p20.json", "r01_pmc_hbm_traffic_2p20.json"):
-                    path = os.path.join(ROOT, "profiles", name)
-                    if os.path.exists(path):
-                        traffic = json.load(open(path))["kernels"][dom]["hbm_bytes_per_launch_raw"]
-                        break
-        except Exception:
-            traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": traffic,
-                "avg_launch_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": alg}
-        # all kernels of one proof (separate steps, one proof in flight, every launch bracketed by events)
-        extra["kernel_ms_per_proof"] = {k: round(kern_all[k] * calls[k], 4) for k in sorted(kern_all)}
-        # G1-adds/sec: one stand-alone registered G1 MSM (witness x pointsA1), all phases, HIP-event timed
-        hA = ctx.register_points(1, zkey.pPoints.pointsA1, zkey.header.nvars)
-        c, W = hA.info()
+    state.update(zkey=zkey, wits=wits, mask=mask, proofs=proofs, ctx=ctx, value=value, dt=dt, value_other=value_other,
+                 lat_ms=lat_ms, inflight=inflight, shard=shard)
+    if rank != 0:
+        return
+    # ---- roofline of the dominant kernel (rank 0; nothing else runs on this GPU from here on) -------------------------
+    extra = {}
+    kern = {k: v["total_ms"] / v["calls"] for k, v in rep.items()}
+    dom = max(rep, key=lambda k: rep[k]["total_ms"])
+    nsh = (n // world) if shard else n
+    # algorithmic bytes of one launch: a G1 MSM reads 32+64 B per pair, a G2 MSM 32+128 B
+    alg = (160 if dom.endswith("g2") else 96) * nsh
+    # The same kernel with the GPU to itself: `reps` stand-alone registered MSMs over the same point array and the
+    # same witness, every launch bracketed by HIP events on its stream, with the clock probe spinning beside them.
+    reps = 5
+    grp = 2 if dom.endswith("g2") else 1
+    pts = zkey.pPoints.pointsB2 if grp == 2 else zkey.pPoints.pointsA1
+    hA = ctx.register_points(grp, pts, zkey.header.nvars)
+    c, W = hA.info()
+    ctx.msm_points(hA, d_w[0].data_ptr(), mont=False, device=True)
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.clock_probe_start(int(reps * 8000))          # longer than the launches it brackets (one G2 MSM: ~6 ms)
+    t1 = time.perf_counter()
+    for _ in range(reps):
         ctx.msm_points(hA, d_w[0].data_ptr(), mont=False, device=True)
-        ctx.profile(True)
-        ctx.profile_reset()
-        for _ in range(reps):
-            ctx.msm_points(hA, d_w[0].data_ptr(), mont=False, device=True)
-        rep1 = ctx.profile_report()
-        ctx.profile(False)
-        hA.release()
-        g1 = sum(v["total_ms"] for v in rep1.values()) / reps
+    msm_wall = (time.perf_counter() - t1) / reps * 1e3
+    clock_ghz = ctx.clock_probe_read()
+    rep1 = ctx.profile_report()
+    ctx.profile(False)
+    hA.release()
+    iso = rep1[dom]["total_ms"] / rep1[dom]["calls"]
+    achieved = alg / (iso * 1e-3) / 1e9
+    static = static_inputs(args, shard, dom)
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 6), "traffic": static["traffic"],
+            "avg_launch_ms": round(iso, 4), "launches_timed": rep1[dom]["calls"],
+            "algorithmic_bytes_per_launch": alg,
+            "contended_launch_ms_in_timed_region": round(kern[dom], 4),
+            "inputs_from": static["traffic_from"],
+            "note": ("avg_launch_ms: HIP events on the launch stream, this kernel ALONE on the GPU (stand-alone MSMs of "
+                     "the same points and witness right after the timed region); contended_...: the same events inside "
+                     "the timed region, where ~15 streams share the CUs -- overlapped wall time, not a per-step cost. "
+                     "MSM is integer-ALU-bound (254-bit Montgomery madds), not HBM-bound: see roofline_valu")}
+    g1 = sum(v["total_ms"] for v in rep1.values()) / reps
+    if grp == 1:
         adds = n * W + 2 * (1 << (c - 1))     # bucket additions + running-sum reduction (one merged bucket set)
         extra["msm_g1_adds_per_sec"] = round(adds / (g1 * 1e-3), 1)
         extra["msm_g1_pairs_per_sec"] = round(n / (g1 * 1e-3), 1)
         extra["msm_g1_ms"] = round(g1, 4)
-        iso = None
-        if dom in rep1:     # the same kernel with the GPU to itself (no other lane / proof in flight)
-            iso = rep1[dom]["total_ms"] / rep1[dom]["calls"]
-            roof["isolated_launch_ms"] = round(iso, 4)
-            roof["achieved_isolated"] = round(alg / (iso * 1e-3) / 1e9, 3)
-        roof["note"] = ("MSM is integer-ALU-bound (254-bit Montgomery madds), not HBM-bound: see roofline_valu and "
-                        "DESIGN.md.  avg_launch_ms is the HIP-event duration inside the timed region, where this "
-                        "kernel shares the GPU with the other MSM lanes and in-flight proofs")
-        extra["msm_window_bits"] = c
-        extra["msm_tables"] = W
-        extra["roofline_valu"] = valu_roofline(dom, iso, n * W if not shard else None)
+    extra["msm_window_bits"] = c
+    extra["msm_tables"] = W
+    # stand-alone kernel times of that MSM (one MSM alone on the GPU; a proof runs five of them on five streams)
+    extra["kernel_ms_standalone_msm_g%d" % grp] = {k: round(v["total_ms"] / reps, 4) for k, v in sorted(rep1.items())}
+    extra["standalone_msm_wall_ms"] = round(msm_wall, 4)
+    extra["roofline_valu"] = valu_roofline(dom, iso, clock_ghz, static)
+    state.update(roof=roof, extra=extra)
 
-    # ---- correctness gate + CPU baseline (oracle = checker / baseline only) ----------------------------------
-    cpu = None
-    if rank == 0:
-        from tests.oracle_c import load_oracle
-        from tests.parity import check_gpu_proof
-        orc = load_oracle()
-        cpu_s = []
-        for k in range(NWITNESS):
-            if proofs[k] is None:
-                raise SystemExit(f"FAIL: witness {k} was never proved")
+
+def static_inputs(args, shard, dom):
+    """Per-launch quantities that only a rocprofv3 counter pass can deliver (HBM bytes, VALU wave-instructions): read
+    from the committed files of THIS build -- every file names the library hash it was measured on, and anything
+    measured on another build is dropped (null) rather than reported as if it belonged to this run."""
+    out = {"traffic": None, "traffic_from": None, "valu": None, "valu_from": None}
+    if args.log2n != 20 or shard:
+        return out
+    sha = lib_sha16()
+    for key, names in (("traffic", ("r03_pmc_hbm_traffic_2p20.json",)), ("valu", ("r03_valu_roofline_inputs.json",))):
+        for name in names:
+            path = os.path.join(ROOT, "profiles", name)
             try:
-                cpu_s.append(check_gpu_proof(orc, zkey, wits[k], F.frSeqToMontBytes(wits[k]), mask.r, mask.s, proofs[k],
-                                             ctx))
-            except AssertionError as e:
-                raise SystemExit(f"FAIL (witness {k}): {e}")
-        log(f"[bench] correctness gate passed for {NWITNESS} distinct witnesses: GPU proof == CPU oracle proof "
-            f"(bit-exact), pairing check ok (oracle and GPU verifier)")
-        if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
-            mean_s = sum(cpu_s) / len(cpu_s)
-            cpu = {"value": round(1.0 / mean_s, 5), "unit": "proofs/s", "cores": orc.cores(), "kind": "port",
-                   "sample": f"{len(cpu_s)} full proofs (buildABC + 6 NTT + 4 G1 MSM + 1 G2 MSM), domain "
-                             f"2^{args.log2n}, {mean_s:.1f}s each; C restatement, NOT constantine"}
+                d = json.load(open(path))
+                if d.get("lib_sha16") != sha:
+                    out[key + "_from"] = {"file": "profiles/" + name, "dropped": "measured on another build "
+                                          f"({d.get('lib_sha16')}, this run: {sha})"}
+                    continue
+                if key == "traffic":
+                    out["traffic"] = d["kernels"][dom]["hbm_bytes_per_launch_raw"]
+                else:
+                    out["valu"] = d
+                out[key + "_from"] = {"file": "profiles/" + name, "lib_sha16": sha, "git": d.get("git"),
+                                      "box": d.get("box")}
+                break
+            except Exception:
+                continue
+    return out
 
-    if rank == 0:
-        where = "host (pinned, .wtns layout)" if args.witness == "host" else "HBM"
-        out = {
-            "metric": "proofs/sec (BN254 Groth16, 2^20-constraint circuit)" if args.log2n == 20 else
-                      f"proofs/sec (BN254 Groth16, 2^{args.log2n} domain)",
-            "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if shard else "weak", "vs_baseline": None,
-            "dtype": "u32 (254-bit Montgomery: 8x32-bit limbs; 9x29-bit limbs in the bucket accumulation)",
-            "data": "synthetic",
-            "config": {"workload": f"BN254 2^{args.log2n}-constraint synthetic R1CS (squaring chain, m=2^{args.log2n}-2), "
-                                   "full prove: buildABC + 6 NTT + 4 G1 MSM + 1 G2 MSM, snarkjs flavour, 1 proof/step/GPU"
-                                   f" ({inflight} proofs in flight per GPU, one shared key)"
-                                   if not shard else
-                                   f"BN254 2^{args.log2n}-constraint synthetic R1CS, ONE proof per step, MSMs point-sharded "
-                                   f"over {world} GPUs + all-gather of partials, quotient {args.quotient}",
-                       "mode": "shard" if shard else "replica", "nvars": zkey.header.nvars,
-                       "domain_log2": args.log2n,
-                       "inputs": f"proving key resident in HBM, witness from {where}, rotating over {NWITNESS} "
-                                 "distinct satisfying witnesses"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        other = "value_witness_in_hbm" if args.witness == "host" else "value_witness_from_host"
-        extra[other] = round(value_other, 4)
-        extra["proof_latency_ms_single_in_flight"] = round(lat_ms, 3)
-        extra["proofs_in_flight_per_gpu"] = inflight
-        extra["keys_resident_per_gpu"] = 1
-        out.update(extra)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def finish_rank0(args, world, st):
+    """correctness gate + CPU baseline (oracle = checker / baseline only), then the ONE JSON line"""
+    from nim_groth16_amd import bn128 as F
+    from tests.oracle_c import load_oracle
+    from tests.parity import check_gpu_proof
+    zkey, wits, mask, proofs, ctx = st["zkey"], st["wits"], st["mask"], st["proofs"], st["ctx"]
+    shard, inflight = st["shard"], st["inflight"]
+    orc = load_oracle()
+    cpu_s = []
+    for k in range(NWITNESS):
+        if proofs[k] is None:
+            raise SystemExit(f"FAIL: witness {k} was never proved")
+        try:
+            cpu_s.append(check_gpu_proof(orc, zkey, wits[k], F.frSeqToMontBytes(wits[k]), mask.r, mask.s, proofs[k], ctx))
+        except AssertionError as e:
+            raise SystemExit(f"FAIL (witness {k}): {e}")
+    log(f"[bench] correctness gate passed for {NWITNESS} distinct witnesses: GPU proof == CPU oracle proof "
+        f"(bit-exact), pairing check ok (oracle and GPU verifier)")
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
+        mean_s = sum(cpu_s) / len(cpu_s)
+        cpu = {"value": round(1.0 / mean_s, 5), "unit": "proofs/s", "cores": orc.cores(), "kind": "port",
+               "sample": f"{len(cpu_s)} full proofs (buildABC + 6 NTT + 4 G1 MSM + 1 G2 MSM), domain "
+                         f"2^{args.log2n}, {mean_s:.1f}s each; C restatement, NOT constantine"}
+    where = "host (pinned, .wtns layout)" if args.witness == "host" else "HBM"
+    out = {
+        "metric": "proofs/sec (BN254 Groth16, 2^20-constraint circuit)" if args.log2n == 20 else
+                  f"proofs/sec (BN254 Groth16, 2^{args.log2n} domain)",
+        "value": round(st["value"], 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(st["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if shard else "weak", "vs_baseline": None,
+        "dtype": "u32 (254-bit Montgomery: 8x32-bit limbs; 9x29-bit limbs in the bucket accumulation)",
+        "data": "synthetic",
+        "config": {"workload": f"BN254 2^{args.log2n}-constraint synthetic R1CS (squaring chain, m=2^{args.log2n}-2), "
+                               "full prove: buildABC + 6 NTT + 4 G1 MSM + 1 G2 MSM, snarkjs flavour, 1 proof/step/GPU"
+                               f" ({inflight} proofs in flight per GPU, one shared key)"
+                               if not shard else
+                               f"BN254 2^{args.log2n}-constraint synthetic R1CS, ONE proof per step, MSMs point-sharded "
+                               f"over {world} GPUs + all-gather of partials, quotient {args.quotient}, {inflight} "
+                               "sharded proofs in flight",
+                   "mode": "shard" if shard else "replica", "nvars": zkey.header.nvars,
+                   "domain_log2": args.log2n,
+                   "inputs": f"proving key resident in HBM, witness from {where}, rotating over {NWITNESS} "
+                             "distinct satisfying witnesses"},
+        "roofline": st.get("roof"), "cpu_baseline": cpu,
+    }
+    extra = st.get("extra", {})
+    other = "value_witness_in_hbm" if args.witness == "host" else "value_witness_from_host"
+    extra[other] = round(st["value_other"], 4)
+    extra["proof_latency_ms_single_in_flight"] = round(st["lat_ms"], 3)
+    extra["proofs_in_flight_per_gpu"] = inflight
+    extra["keys_resident_per_gpu"] = 1
+    extra["lib_sha16"] = lib_sha16()
+    out.update(extra)
+    print(json.dumps(out), flush=True)
 
 
 def dry_run(args, rank, world):
@@ -396,32 +495,35 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
-def valu_roofline(dom, isolated_ms, madds):
-    """The ALU-side roofline of the dominant kernel, from the committed PMC / micro-benchmark measurements
-    (profiles/r02_valu_roofline_inputs.json, produced by tools/valu_roofline.py from rocprofv3 --pmc passes and the
-    real-cycle micro-benchmarks) and this run's isolated launch duration.  None when the inputs are missing."""
-    path = os.path.join(ROOT, "profiles", "r02_valu_roofline_inputs.json")
-    if isolated_ms is None or not os.path.exists(path):
-        return None
-    try:
-        inp = json.load(open(path))
-        k = inp["kernels"][dom]
-        simds = 1024
-        clock = k["sustained_clock_ghz"]
-        wave_insts = k["valu_wave_insts_per_launch"]
-        mix_cyc = k["mix_issue_cycles_per_inst"]           # instruction-mix-weighted issue cost, real cycles
-        mad_insts = k["mad_u64_wave_insts_per_launch"]
-        mad_cyc = inp["issue_cycles"]["v_mad_u64_u32"]
-        t_mix = wave_insts / simds * mix_cyc / (clock * 1e9) * 1e3
-        t_mul = mad_insts / simds * mad_cyc / (clock * 1e9) * 1e3
-        return {"bound": "valu-issue", "kernel": dom, "achieved_ms": round(isolated_ms, 4),
-                "valu_wave_insts_per_launch": wave_insts, "mad_u64_wave_insts_per_launch": mad_insts,
-                "sustained_clock_ghz": clock, "mix_issue_cycles_per_inst": mix_cyc,
-                "mad_u64_issue_cycles": mad_cyc, "bound_ms_mix": round(t_mix, 4), "frac_mix": round(t_mix / isolated_ms, 4),
-                "bound_ms_multiply_only": round(t_mul, 4), "frac_multiply_only": round(t_mul / isolated_ms, 4),
-                "source": "profiles/r02_valu_roofline_inputs.json"}
-    except Exception:
-        return None
+def valu_roofline(dom, isolated_ms, clock_ghz, static):
+    """The ALU-side roofline of the dominant kernel.  This run contributes the isolated launch duration and the
+    shader clock the chip sustained during those launches (g16_clock_probe: s_memtime / s_memrealtime of a wave
+    spinning beside them); the VALU wave-instruction counts of one launch and the issue costs per instruction class
+    come from the committed counter pass / micro-benchmarks of this very build (static_inputs drops them otherwise)."""
+    inp = static.get("valu") if static else None
+    if isolated_ms is None or not inp or dom not in inp.get("kernels", {}):
+        return {"bound": "valu-issue", "kernel": dom, "achieved_ms": None if isolated_ms is None else round(isolated_ms, 4),
+                "sustained_clock_ghz": round(clock_ghz, 4) if clock_ghz else None, "frac_mix": None,
+                "frac_multiply_only": None, "inputs_from": static.get("valu_from") if static else None,
+                "note": "no counter pass of this build is committed: instruction counts withheld"}
+    k = inp["kernels"][dom]
+    simds = 1024
+    clock = clock_ghz if clock_ghz and clock_ghz > 0.5 else k["sustained_clock_ghz"]
+    wave_insts = k["valu_wave_insts_per_launch"]
+    mix_cyc = k["mix_issue_cycles_per_inst"]           # instruction-mix-weighted issue cost, real cycles
+    mad_insts = k["mad_u64_wave_insts_per_launch"]
+    mad_cyc = inp["issue_cycles"]["v_mad_u64_u32"]
+    t_mix = wave_insts / simds * mix_cyc / (clock * 1e9) * 1e3
+    t_mul = mad_insts / simds * mad_cyc / (clock * 1e9) * 1e3
+    return {"bound": "valu-issue", "kernel": dom, "achieved_ms": round(isolated_ms, 4),
+            "valu_wave_insts_per_launch": wave_insts, "mad_u64_wave_insts_per_launch": mad_insts,
+            "sustained_clock_ghz": round(clock, 4),
+            "clock_source": "g16_clock_probe during this run's isolated launches" if clock is clock_ghz else
+                            "counter pass (GRBM_GUI_ACTIVE / duration)",
+            "mix_issue_cycles_per_inst": mix_cyc, "mad_u64_issue_cycles": mad_cyc,
+            "bound_ms_mix": round(t_mix, 4), "frac_mix": round(t_mix / isolated_ms, 4),
+            "bound_ms_multiply_only": round(t_mul, 4), "frac_multiply_only": round(t_mul / isolated_ms, 4),
+            "inputs_from": static.get("valu_from")}
 
 
 if __name__ == "__main__":

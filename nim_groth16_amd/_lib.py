@@ -15,7 +15,7 @@ PARTIALS_BYTES = 768
 # every symbol include/g16hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_last_error", "g16_ctx_set_stream", "g16_ctx_synchronize",
-    "g16_selftest", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
+    "g16_selftest", "g16_clock_probe_start", "g16_clock_probe_read", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
     "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_inf_count", "g16_points_info", "g16_msm_points",
@@ -85,6 +85,8 @@ def load_library():
     lib.g16_ctx_set_stream.argtypes = [vp, vp]
     lib.g16_ctx_synchronize.argtypes = [vp]
     lib.g16_selftest.argtypes = [vp]
+    lib.g16_clock_probe_start.argtypes = [vp, u32]
+    lib.g16_clock_probe_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     for name in ("g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
                  "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev"):
         getattr(lib, name).argtypes = [vp, vp, u32, vp, sz, vp]
@@ -183,6 +185,16 @@ class Context:
 
     def selftest(self):
         self._check(self._lib.g16_selftest(self._h))
+
+    def clock_probe_start(self, micros: int):
+        """one wave spins for `micros` us beside the context's next launches (g16_clock_probe_start)"""
+        self._check(self._lib.g16_clock_probe_start(self._h, micros))
+
+    def clock_probe_read(self) -> float:
+        """-> the shader clock (GHz) the chip sustained while the probe ran"""
+        g = ctypes.c_double()
+        self._check(self._lib.g16_clock_probe_read(self._h, ctypes.byref(g)))
+        return g.value
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.g16_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr)))

@@ -25,7 +25,8 @@ struct G16Env {
   int red_slice_log2 = 0;  // G16_RED_SLICE    log2 of the chunks per reduce2 slice of a merged bucket set (8..11)
   int inf_compact_pct = 10;   // G16_INF_COMPACT  point sets with at least this percentage of (0,0) points get their own
                               // entry lists without them (0: always, 101: never); prover.hip
-  int r2_width = 1;        // G16_R2_WIDTH  0: reduce2 with 512 / 256-thread workgroups, 1: 128 / 64, 2: 64 / 64 (msm_stage.cuh)
+  int r2_width = -1;       // G16_R2_WIDTH  0: reduce2 with 512 / 256-thread workgroups, 1: 128 / 64, 2: 64 / 64; unset:
+                           // narrow inside proofs, wide for stand-alone MSMs (msm_stage.cuh)
   int ntt_tile = 2048;            // G16_NTT_TILE = 1024 | 2048 | 4096: NTT workgroup geometry (ntt.cuh)
   // launch order of a proof (experiments; the defaults are the measured optimum, tools/ab_schedule.sh):
   int quotient_first = 0;         // G16_QUOTIENT_FIRST=1: enqueue buildABC + quotient + sort(qs) before the witness MSMs
@@ -54,6 +55,7 @@ struct g16_ctx {
   struct MsmSort {
     Buf buf;
     g16::MsmParams P;
+    bool narrow_tail = false;   // reduce2 geometry: see stage_reduce2_fold (set by the prover's lanes: throughput)
     uint32_t *count = nullptr, *cursor = nullptr, *offset = nullptr, *xoff = nullptr, *heavy = nullptr,
              *info = nullptr, *entries = nullptr, *perm = nullptr, *ghist = nullptr, *blk_base = nullptr, *tile_hist = nullptr;
     uint2* tmp = nullptr;
@@ -81,6 +83,8 @@ struct g16_ctx {
   Buf prove;     // per-proof scalars: witness, Az|Bz|Cz, qs
   Buf fb_table[2];  // fixed-base tables of gen1 / gen2
   bool fb_ready[2] = {false, false};
+  hipStream_t probe_stream = nullptr;   // g16_clock_probe_*
+  uint64_t* probe_out = nullptr;
   const void* shard_begun = nullptr;   // key of a g16_prove_partials_begin that still awaits its _end
   uint32_t tw_log2n = 0xffffffffu;
   uint32_t coset_log2n[2] = {0xffffffffu, 0xffffffffu};

@@ -51,6 +51,7 @@ int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, c
 // one complete MSM on the context's main stream
 static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
                           void* d_out_aff, void* d_out_acc, uint32_t table_c, const uint32_t* d_live) {
+  ctx->sort[0].narrow_tail = false;   // stand-alone MSM: nothing overlaps its tail, the short chain wins
   int32_t rc = msm_sort_device(ctx, ctx->stream, d_scalars, flags, n, table_c, ctx->sort[0], d_live);
   if (rc) return rc;
   if (table_c == 0 && n) {   // plain point array: the accumulate kernel reads reduced-radix entries

@@ -77,15 +77,16 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::M
   // threads: one chunk per thread) have the shortest chain; narrow ones (128 / 64 threads: four chunks per thread,
   // work-efficient serial sums, a 7- / 6-step scan) issue ~2.5x fewer wave-instructions for a ~20 % longer chain.
   // A proof's throughput is bound by instruction issue over ALL its kernels (same-box A/B, profiles/r03_ab_knobs.txt:
-  // 111.6 -> 114.7 proofs/s, single-proof latency 11.67 -> 11.85 ms), so narrow is the default;
-  // G16_R2_WIDTH=0 selects the wide geometry (lowest single-MSM latency), 2 a single wave per slice.
+  // 111.6 -> 114.7 proofs/s, single-proof latency 11.67 -> 11.85 ms), so the prover's lanes use narrow; a stand-alone
+  // MSM (g16_msm_*: the msmMultiThreaded drop-in, nothing to overlap with) keeps wide: a 2^20 G2 MSM is 5.25 ms wide,
+  // 5.7 ms narrow.  G16_R2_WIDTH = 0 / 1 / 2 forces wide / narrow / a single wave per slice everywhere.
   constexpr int R2B = sizeof(typename C::Aff) == 64 ? 512 : 256;
   constexpr int R2N = R2B / 4;
   const auto* cR = (const typename C::Acc*)chunkR;
   const auto* cA = (const typename C::Acc*)chunkA;
   const uint32_t cps = (uint32_t)(nchunks / nsets);
   const char* nm = g2 ? "msm_reduce2_g2" : "msm_reduce2_g1";
-  switch (g16_env().r2_width) {
+  switch (g16_env().r2_width >= 0 ? g16_env().r2_width : (S.narrow_tail ? 1 : 0)) {
     case 0:
       KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), nsets, R2B, R2B * sizeof(typename C::Acc), cR, cA, cps, wsum, wtot);
       break;

@@ -357,6 +357,7 @@ static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, uint32_t fla
     const int la = g16_env().g1_lanes[0], lb = g16_env().g1_lanes[1], lc = g16_env().g1_lanes[2];
     const u256* d_wr = b.d_w + k->w_lo;
     HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
+    for (auto& srt : ctx->sort) srt.narrow_tail = true;   // proofs overlap their MSM tails with other work (msm_stage.cuh)
     if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
     for (int i = 1; i < 4; ++i)   // (lane 1 sorts for itself when B is sparse: it needs the witness, not lane 0's sort)
@@ -394,6 +395,7 @@ static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, uint32_t fla
 // five partials.  d_qs_slice: the H scalars of [h_lo, h_hi), Montgomery.
 static int32_t launch_h_sort(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice) {
   const size_t nh = k->h_hi - k->h_lo;
+  ctx->sort[1].narrow_tail = true;
   return nh ? g16_msm_sort(ctx, ctx->stream, d_qs_slice, G16_SCALARS_MONT, nh, k->H1->c, ctx->sort[1]) : G16_OK;
 }
 static int32_t launch_h_and_collect(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice, uint32_t flags,

@@ -34,11 +34,15 @@ def test_valu_roofline_inputs_are_consistent():
     k = inp["kernels"]["msm_accum_g1"]
     assert 0.5 < k["mad_u64_share_of_valu"] < 0.7 and 3.5 < k["mix_issue_cycles_per_inst"] < 4.5
     assert 4.0 < inp["issue_cycles"]["v_mad_u64_u32"] < 5.0 and 1.8 < k["sustained_clock_ghz"] < 2.5
-    r = bench.valu_roofline("msm_accum_g1", k["duration_us"] / 1e3, None)
+    r = bench.valu_roofline("msm_accum_g1", k["duration_us"] / 1e3, k["sustained_clock_ghz"],
+                            {"valu": inp, "valu_from": {"file": "profiles/r02_valu_roofline_inputs.json"}})
     for key in ("bound", "achieved_ms", "valu_wave_insts_per_launch", "sustained_clock_ghz", "bound_ms_mix", "frac_mix",
                 "bound_ms_multiply_only", "frac_multiply_only"):
         assert key in r, key
     assert abs(r["frac_mix"] - k["frac_mix"]) < 0.01 and r["frac_multiply_only"] < r["frac_mix"] < 1.0
+    # inputs measured on another build are withheld, not silently reused
+    r = bench.valu_roofline("msm_accum_g1", 0.9, 2.0, {"valu": None, "valu_from": {"dropped": "other build"}})
+    assert r["frac_mix"] is None and r["sustained_clock_ghz"] == 2.0
 
 
 def test_bench_source_emits_the_same_keys():

@@ -43,6 +43,22 @@ def _rank(rank, world, port, q, quotient):
         vals = F.frSeqToStdBytes(wit) if std else F.frSeqToMontBytes(wit)
         pr = sp.prove(Witness("bn128", len(wit), vals, std=std), Mask(r, s))
         out.append((pr.pi_a, pr.pi_b, pr.pi_c, pr.publicIO))
+    # the pipeline: five proofs through submit / collect with two in flight (two contexts on this rank's key shard,
+    # proof i's begin + scatters issued before proof i-1's end + all-gather); masks alternate so that neighbours differ
+    wb = F.frSeqToMontBytes(wit)
+    rb, sb = F.frToMontBytes(r), F.frToMontBytes(s)
+    masks = [(rb, sb), (sb, rb), (rb, sb), (None, None), (sb, rb)]
+    piped = []
+    for (mr, ms) in masks:
+        done = sp.submit(wb, True, mr, ms)
+        if done is not None:
+            piped.append(done)
+    assert len(piped) == len(masks) - sp.depth and sp.depth == 2
+    piped += sp.collect()
+    single = {m: sp.prove_raw(wb, True, *m) for m in set(masks)}
+    assert piped == [single[m] for m in masks], "pipelined proofs differ from the one-at-a-time proofs"
+    assert piped[0] == out[0][:3]
+    sp.close()
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
