@@ -341,7 +341,7 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     # algorithmic bytes of one launch: a G1 MSM reads 32+64 B per pair, a G2 MSM 32+128 B
     alg = (160 if dom.endswith("g2") else 96) * nsh
     # The same kernel with the GPU to itself: `reps` stand-alone registered MSMs over the same point array and the
-    # same witness, every launch bracketed by HIP events on its stream, with the clock probe spinning beside them.
+    # same witness, every launch bracketed by HIP events on its stream and stamping the shader clock from inside.
     reps = 5
     grp = 2 if dom.endswith("g2") else 1
     pts = zkey.pPoints.pointsB2 if grp == 2 else zkey.pPoints.pointsA1
@@ -350,12 +350,12 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     ctx.msm_points(hA, d_w[0].data_ptr(), mont=False, device=True)
     ctx.profile(True)
     ctx.profile_reset()
-    ctx.clock_probe_start(int(reps * 8000))          # longer than the launches it brackets (one G2 MSM: ~6 ms)
+    ctx.profile_clock()                              # reset the in-kernel clock sums
     t1 = time.perf_counter()
     for _ in range(reps):
         ctx.msm_points(hA, d_w[0].data_ptr(), mont=False, device=True)
     msm_wall = (time.perf_counter() - t1) / reps * 1e3
-    clock_ghz = ctx.clock_probe_read()
+    clock_ghz = ctx.profile_clock()                  # s_memtime / s_memrealtime inside those launches
     rep1 = ctx.profile_report()
     ctx.profile(False)
     hA.release()
@@ -497,8 +497,8 @@ def dry_run(args, rank, world):
 
 def valu_roofline(dom, isolated_ms, clock_ghz, static):
     """The ALU-side roofline of the dominant kernel.  This run contributes the isolated launch duration and the
-    shader clock the chip sustained during those launches (g16_clock_probe: s_memtime / s_memrealtime of a wave
-    spinning beside them); the VALU wave-instruction counts of one launch and the issue costs per instruction class
+    shader clock the chip sustained during those launches (g16_profile_clock: s_memtime / s_memrealtime stamped
+    by the kernel's own workgroups); the VALU wave-instruction counts of one launch and the issue costs per instruction class
     come from the committed counter pass / micro-benchmarks of this very build (static_inputs drops them otherwise)."""
     inp = static.get("valu") if static else None
     if isolated_ms is None or not inp or dom not in inp.get("kernels", {}):
@@ -518,7 +518,7 @@ def valu_roofline(dom, isolated_ms, clock_ghz, static):
     return {"bound": "valu-issue", "kernel": dom, "achieved_ms": round(isolated_ms, 4),
             "valu_wave_insts_per_launch": wave_insts, "mad_u64_wave_insts_per_launch": mad_insts,
             "sustained_clock_ghz": round(clock, 4),
-            "clock_source": "g16_clock_probe during this run's isolated launches" if clock is clock_ghz else
+            "clock_source": "s_memtime / s_memrealtime inside this run's isolated launches (g16_profile_clock)" if clock is clock_ghz else
                             "counter pass (GRBM_GUI_ACTIVE / duration)",
             "mix_issue_cycles_per_inst": mix_cyc, "mad_u64_issue_cycles": mad_cyc,
             "bound_ms_mix": round(t_mix, 4), "frac_mix": round(t_mix / isolated_ms, 4),

@@ -64,12 +64,6 @@ int32_t g16_ctx_synchronize(g16_ctx* ctx);
 /* layout / constant / arithmetic self-check on the device (sizeof, Montgomery one == frMontR io.nim:91,
  * gen1 on curve, small known-answer MSM and NTT).  The Nim shim calls it once at start-up. */
 int32_t g16_selftest(g16_ctx* ctx);
-/* Shader-clock probe (measurement aid): _start launches one wave on a stream of its own that spins for `micros`
- * microseconds beside whatever this context runs next and stamps s_memtime / s_memrealtime around the loop;
- * _read waits for it and returns d_memtime / d_memrealtime * 100 MHz in GHz -- the clock the chip sustained under
- * that load.  bench.py brackets the isolated launches of the dominant kernel with it (roofline_valu). */
-int32_t g16_clock_probe_start(g16_ctx* ctx, uint32_t micros);
-int32_t g16_clock_probe_read(g16_ctx* ctx, double* ghz);
 
 /* ---- MSM: replaces msmMultiThreadedG1/G2 (groth16/bn128/msm.nim:89-158) and msmG1/msmG2 (:202-203),
  *      i.e. constantine's multiScalarMul_vartime + prj.affine (msm.nim:49-54, 76-81) ----------------- */
@@ -271,6 +265,10 @@ int32_t g16_profile_enable(g16_ctx* ctx, int32_t on);
 int32_t g16_profile_reset(g16_ctx* ctx);
 /* writes a JSON object {"kernel": {"calls": k, "total_ms": t}, ...} into buf (NUL-terminated) */
 int32_t g16_profile_report(g16_ctx* ctx, char* buf, size_t buflen);
+/* The shader clock (GHz) the chip sustained while the bucket-accumulation kernels launched since the last call ran
+ * (profiling on): sum of s_memtime deltas / sum of s_memrealtime deltas over thread 0 of every workgroup.  0 if none
+ * ran.  Waits for the context's work; resets the sums. */
+int32_t g16_profile_clock(g16_ctx* ctx, double* ghz);
 
 #ifdef __cplusplus
 }

@@ -15,14 +15,14 @@ PARTIALS_BYTES = 768
 # every symbol include/g16hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "g16_ctx_create", "g16_ctx_destroy", "g16_last_error", "g16_ctx_set_stream", "g16_ctx_synchronize",
-    "g16_selftest", "g16_clock_probe_start", "g16_clock_probe_read", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
+    "g16_selftest", "g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
     "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev", "g16_g1_sum_partials", "g16_g2_sum_partials",
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_inf_count", "g16_points_info", "g16_msm_points",
     "g16_points_check_g1", "g16_points_check_g2", "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
     "g16_pkey_destroy", "g16_pkey_inf_counts", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
     "g16_prove_partials_begin", "g16_prove_partials_end",
-    "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report",
+    "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report", "g16_profile_clock",
     "g16_vkey_create", "g16_vkey_destroy", "g16_verify", "g16_pairing",
 ]
 VERIFY_SUBGROUP = 16
@@ -85,8 +85,6 @@ def load_library():
     lib.g16_ctx_set_stream.argtypes = [vp, vp]
     lib.g16_ctx_synchronize.argtypes = [vp]
     lib.g16_selftest.argtypes = [vp]
-    lib.g16_clock_probe_start.argtypes = [vp, u32]
-    lib.g16_clock_probe_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     for name in ("g16_msm_g1", "g16_msm_g2", "g16_msm_g1_dev", "g16_msm_g2_dev",
                  "g16_msm_g1_partial_dev", "g16_msm_g2_partial_dev"):
         getattr(lib, name).argtypes = [vp, vp, u32, vp, sz, vp]
@@ -129,6 +127,7 @@ def load_library():
     lib.g16_profile_enable.argtypes = [vp, i32]
     lib.g16_profile_reset.argtypes = [vp]
     lib.g16_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
+    lib.g16_profile_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     for name in SYMBOLS:
         if name not in ("g16_ctx_destroy", "g16_last_error", "g16_points_release", "g16_points_count",
                         "g16_points_inf_count",
@@ -185,16 +184,6 @@ class Context:
 
     def selftest(self):
         self._check(self._lib.g16_selftest(self._h))
-
-    def clock_probe_start(self, micros: int):
-        """one wave spins for `micros` us beside the context's next launches (g16_clock_probe_start)"""
-        self._check(self._lib.g16_clock_probe_start(self._h, micros))
-
-    def clock_probe_read(self) -> float:
-        """-> the shader clock (GHz) the chip sustained while the probe ran"""
-        g = ctypes.c_double()
-        self._check(self._lib.g16_clock_probe_read(self._h, ctypes.byref(g)))
-        return g.value
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.g16_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
@@ -293,6 +282,12 @@ class Context:
 
     def profile_reset(self):
         self._check(self._lib.g16_profile_reset(self._h))
+
+    def profile_clock(self) -> float:
+        """shader clock (GHz) sustained while the accumulate kernels since the last call ran (profiling on); 0 if none"""
+        g = ctypes.c_double()
+        self._check(self._lib.g16_profile_clock(self._h, ctypes.byref(g)))
+        return g.value
 
     def profile_report(self) -> dict:
         buf = ctypes.create_string_buffer(1 << 16)

@@ -83,8 +83,7 @@ struct g16_ctx {
   Buf prove;     // per-proof scalars: witness, Az|Bz|Cz, qs
   Buf fb_table[2];  // fixed-base tables of gen1 / gen2
   bool fb_ready[2] = {false, false};
-  hipStream_t probe_stream = nullptr;   // g16_clock_probe_*
-  uint64_t* probe_out = nullptr;
+  unsigned long long* clk_buf = nullptr;   // {sum d_memtime, sum d_memrealtime} of the accumulate kernels (g16_profile_clock)
   const void* shard_begun = nullptr;   // key of a g16_prove_partials_begin that still awaits its _end
   uint32_t tw_log2n = 0xffffffffu;
   uint32_t coset_log2n[2] = {0xffffffffu, 0xffffffffu};

@@ -115,8 +115,7 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
     (void)hipEventDestroy(e.e1);
   }
   for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
-  if (ctx->probe_stream) (void)hipStreamSynchronize(ctx->probe_stream), (void)hipStreamDestroy(ctx->probe_stream);
-  if (ctx->probe_out) (void)hipFree(ctx->probe_out);
+  if (ctx->clk_buf) (void)hipFree(ctx->clk_buf);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -149,6 +148,11 @@ extern "C" int32_t g16_ctx_synchronize(g16_ctx* ctx) {
 
 extern "C" int32_t g16_profile_enable(g16_ctx* ctx, int32_t on) {
   if (!ctx) return G16_EINVAL;
+  CTX_ENTER_KEEP(ctx);
+  if (on && !ctx->clk_buf) {
+    HIPCHK(ctx, hipMalloc((void**)&ctx->clk_buf, 16));
+    HIPCHK(ctx, hipMemset(ctx->clk_buf, 0, 16));
+  }
   ctx->profiling = on != 0;
   ctx->prof_accum_only = on == 2;
   return G16_OK;
@@ -192,52 +196,22 @@ extern "C" int32_t g16_profile_report(g16_ctx* ctx, char* buf, size_t buflen) {
   return G16_OK;
 }
 
-// ---- shader-clock probe ---------------------------------------------------------------------------------
-// One wave spins for `micros` microseconds and stamps the shader clock counter (s_memtime: one tick per shader
-// cycle) and the constant 100 MHz counter (s_memrealtime) around the loop: clock = d_memtime / d_memrealtime * 100 MHz.
-// Started on a stream of its own, it runs BESIDE whatever the context launches next, so the reading is the clock the
-// chip sustains under that load (the clock domain is chip-wide): bench.py brackets its isolated launches of the
-// dominant kernel with it, so that the VALU roofline needs no assumed or imported clock.
-static __global__ void clock_probe_kernel(uint64_t realtime_ticks, uint64_t* out) {
-  if (threadIdx.x != 0) return;
-  const uint64_t r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
-  uint64_t r1 = r0;
-  while (r1 - r0 < realtime_ticks) {
-    __builtin_amdgcn_s_sleep(8);
-    r1 = __builtin_amdgcn_s_memrealtime();
-  }
-  const uint64_t t1 = __builtin_amdgcn_s_memtime();
-  out[0] = t1 - t0;
-  out[1] = r1 - r0;
-}
-extern "C" int32_t g16_clock_probe_start(g16_ctx* ctx, uint32_t micros) {
-  if (!ctx) return G16_EINVAL;
-  if (micros == 0 || micros > 1000000) {
-    ctx->err = "probe duration must be 1 .. 10^6 microseconds";
-    return G16_EINVAL;
-  }
-  CTX_ENTER_KEEP(ctx);
-  if (!ctx->probe_stream) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->probe_stream, hipStreamNonBlocking, hi));
-    HIPCHK(ctx, hipMalloc((void**)&ctx->probe_out, 16));
-  }
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ctx->probe_stream, (uint64_t)micros * 100, ctx->probe_out);
-  HIPCHK(ctx, hipGetLastError());
-  return G16_OK;
-}
-extern "C" int32_t g16_clock_probe_read(g16_ctx* ctx, double* ghz) {
+// ---- sustained shader clock of the accumulate kernels -------------------------------------------------------
+// While profiling is on, thread 0 of every msm_accum workgroup stamps the shader clock counter (s_memtime: one tick
+// per shader cycle) and the constant 100 MHz counter (s_memrealtime) around its task and adds both deltas to two
+// 64-bit sums (msm.cuh).  sum(d_memtime) / sum(d_memrealtime) * 100 MHz is the clock the chip sustained WHILE THAT
+// KERNEL RAN -- the accumulate kernels are power-limited (~2.0 GHz against 2.4 GHz nominal), so the VALU roofline
+// must not borrow a clock from another box, another kernel or the idle gaps between launches.
+extern "C" int32_t g16_profile_clock(g16_ctx* ctx, double* ghz) {
   if (!ctx || !ghz) return G16_EINVAL;
-  if (!ctx->probe_stream) {
-    ctx->err = "g16_clock_probe_read without g16_clock_probe_start";
-    return G16_EINVAL;
-  }
   CTX_ENTER_KEEP(ctx);
-  uint64_t h[2] = {0, 0};
-  HIPCHK(ctx, hipMemcpyAsync(h, ctx->probe_out, 16, hipMemcpyDeviceToHost, ctx->probe_stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->probe_stream));
-  *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+  *ghz = 0.0;
+  if (!ctx->clk_buf) return G16_OK;
+  ctx_quiesce(ctx);
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpy(h, ctx->clk_buf, 16, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemset(ctx->clk_buf, 0, 16));
+  if (h[1]) *ghz = (double)h[0] / (double)h[1] * 0.1;
   return G16_OK;
 }
 

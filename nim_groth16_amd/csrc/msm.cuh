@@ -471,8 +471,13 @@ template <class C>
 __global__ void __launch_bounds__(ACC_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : G16_G2_WAVES)
 msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __restrict__ entries,
           const uint32_t* __restrict__ offset, const uint2* __restrict__ xseg, const uint32_t* __restrict__ info,
-          const uint32_t* __restrict__ perm, MsmParams P, typename Ec29<C>::Acc* __restrict__ partial) {
+          const uint32_t* __restrict__ perm, MsmParams P, typename Ec29<C>::Acc* __restrict__ partial,
+          unsigned long long* __restrict__ clk) {
   using E = Ec29<C>;
+  // profiling only: shader-clock and 100 MHz stamps around thread 0's task (g16_profile_clock)
+  unsigned long long t0 = 0, r0 = 0;
+  const bool stamp = clk != nullptr && threadIdx.x == 0;
+  if (stamp) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   // task order = dispatch order: the extra segments of split buckets (the longest tasks, L entries each)
   // first, then the buckets by descending size, so that no long task is left for the tail of the launch
   const uint32_t t = blockIdx.x * ACC_BLOCK + threadIdx.x;
@@ -498,6 +503,10 @@ msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __re
     E::madd(acc, points + (e & 0x7fffffffu), e >> 31);
   }
   partial[slot] = acc;   // stays in the reduced-radix form: msm_heavy / msm_reduce1 consume it as is
+  if (stamp) {
+    atomicAdd(&clk[0], __builtin_amdgcn_s_memtime() - t0);
+    atomicAdd(&clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+  }
 }
 
 // affine points in the reference layout (64 / 128 B, Montgomery R = 2^256) -> reduced-radix table entries

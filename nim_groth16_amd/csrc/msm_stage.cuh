@@ -14,7 +14,7 @@ static int32_t stage_accum(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort&
   const uint32_t ntask = P.nbuckets + P.max_extra;
   KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + ACC_BLOCK - 1) / ACC_BLOCK,
              ACC_BLOCK, 0, (const typename Ec29<C>::Tab*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
-             (typename Ec29<C>::Acc*)partial);
+             (typename Ec29<C>::Acc*)partial, ctx->profiling ? ctx->clk_buf : (unsigned long long*)nullptr);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }

@@ -87,3 +87,39 @@ def test_snarkjs_laid_out_files_prove_and_verify_python_and_native(ctx, tmp_path
     assert out.returncode == 0 and "verification succeeded" in out.stdout, out.stderr
     assert open(tmp_path / "proof.json").read() == open(tmp_path / "py_proof.json").read()
     assert open(tmp_path / "public.json").read() == open(tmp_path / "py_public.json").read()
+
+
+def test_config5_handoff_recipe_on_external_files(ctx, tmp_path):
+    """tools/prove_files.py -c -y -t -k: the checked recipe for files that arrive from outside (BASELINE config 5:
+    a real circom/snarkjs pair cannot be produced in the build container).  Here the files are a snarkjs-laid-out
+    fixture and a key in which ~90 % of the B points are (0,0); the tool must check every point, prove, verify on the
+    GPU, write proof / public / verification_key JSON, and report the infinity fractions it found."""
+    import sys
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.files import writeWitness, writeZKey
+    from nim_groth16_amd.synthetic import SplitMix64, mixedCircuit
+    from tests.test_files_cpu import _snarkjs_like
+    tool = os.path.join(ROOT, "tools", "prove_files.py")
+
+    def run(zpath, wpath, tag):
+        out = subprocess.run([sys.executable, tool, "-z", zpath, "-w", wpath, "-c", "-y", "-t", "-o",
+                              str(tmp_path / f"{tag}_proof.json"), "-i", str(tmp_path / f"{tag}_public.json"), "-k",
+                              str(tmp_path / f"{tag}_vkey.json")], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "verification succeeded" in out.stdout and "points at infinity (0,0): A1 " in out.stdout
+        pj, vk = json.load(open(tmp_path / f"{tag}_proof.json")), json.load(open(tmp_path / f"{tag}_vkey.json"))
+        assert pj["protocol"] == "groth16" and pj["curve"] == "bn128" and len(pj["pi_b"]) == 3
+        assert vk["protocol"] == "groth16" and len(vk["IC"]) == vk["nPublic"] + 1
+        return out.stdout
+
+    zpath, wpath, _, _, _ = _snarkjs_like(tmp_path)
+    run(zpath, wpath, "fixture")
+    m = (1 << 12) - 2
+    r1cs, wit = mixedCircuit(m, seed=4, zero_pct=0, one_pct=0, lin_pct=90)
+    rng = SplitMix64(9)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
+    z2, w2 = str(tmp_path / "lin.zkey"), str(tmp_path / "lin.wtns")
+    writeZKey(z2, zk)
+    writeWitness(w2, wit)
+    text = run(z2, w2, "lin")
+    assert "B1+B2 compacted" in text and "A1 shared witness sort" in text
