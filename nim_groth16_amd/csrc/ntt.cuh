@@ -90,12 +90,20 @@ __device__ __forceinline__ uint32_t ntt_tile_of_block(uint32_t bid, uint32_t nti
   return (ntiles & 7u) ? bid : (bid & 7u) * (ntiles >> 3) + (bid >> 3);
 }
 
-// rho DIF stages on the tile in LDS (rows r = 0..R-1 of B elements; output row bitrev(q) holds Z_q)
+// rho DIF stages on the tile in LDS (rows r = 0..R-1 of B elements; output row bitrev(q) holds Z_q).
+// Two stages per LDS round trip: a thread takes the four elements {i, i+h/2, i+h, i+3h/2} of a radix-4 group into
+// registers, runs the stage with half-distance h on the pairs (0,2), (1,3) and the stage with half-distance h/2 on
+// (0,1), (2,3), and writes them back -- the same radix-2 butterflies in the same order as the reference recursion
+// (ntt.nim:47-50: t = w^j * odd; (even + t, even - t), here in DIF form), so the results are bit-identical, with half
+// the LDS traffic, half the barriers and half the index arithmetic.  An odd rho starts with one plain radix-2 stage.
+// (A prime field has no cheap 4th root of unity: the multiplication count is unchanged, 4 per group.)
 template <int BLOCK>
 __device__ __forceinline__ void ntt_tile_stages(u256* lds, const u256* twl, uint32_t rho, uint32_t log2b,
                                                 uint32_t tile) {
   const uint32_t tid = threadIdx.x, B = 1u << log2b;
-  for (uint32_t lh = rho; lh-- > 0;) {
+  uint32_t lh = rho;   // stages still to run; the next one has half-distance 2^(lh-1)
+  if (lh & 1u) {
+    --lh;
     const uint32_t h = 1u << lh;
     for (uint32_t bf = tid; bf < (tile >> 1); bf += BLOCK) {
       uint32_t b = bf & (B - 1), pi = bf >> log2b;
@@ -107,6 +115,37 @@ __device__ __forceinline__ void ntt_tile_stages(u256* lds, const u256* twl, uint
       if (p) dif = Fr::mul(dif, twl[p << (rho - lh - 1)]);  // p == 0: twiddle 1
       lds[ia] = sum;
       lds[ib] = dif;
+    }
+    __syncthreads();
+  }
+  while (lh >= 2) {
+    lh -= 2;                              // stage A: half-distance h = 2^(lh+1); stage B: hh = 2^lh
+    const uint32_t hh = 1u << lh, h = hh << 1;
+    const uint32_t sA = rho - lh - 2;     // twiddle stride of stage A: w_(2h)^p = w_R^(p << sA); stage B: << (sA + 1)
+    for (uint32_t g = tid; g < (tile >> 2); g += BLOCK) {
+      const uint32_t b = g & (B - 1), pi = g >> log2b;
+      const uint32_t p = pi & (hh - 1);
+      const uint32_t i = ((pi >> lh) << (lh + 2)) | p;
+      const uint32_t i0 = (i << log2b) | b, i1 = ((i + hh) << log2b) | b, i2 = ((i + h) << log2b) | b,
+                     i3 = ((i + h + hh) << log2b) | b;
+      const u256 x0 = lds[i0], x1 = lds[i1], x2 = lds[i2], x3 = lds[i3];
+      // stage A (distance h): offsets p and p + hh inside the 2h-block
+      u256 a0 = Fr::add(x0, x2), a2 = Fr::sub(x0, x2);
+      u256 a1 = Fr::add(x1, x3), a3 = Fr::sub(x1, x3);
+      if (p) a2 = Fr::mul(a2, twl[p << sA]);
+      a3 = Fr::mul(a3, twl[(p + hh) << sA]);
+      // stage B (distance hh): offset p inside either h-block
+      u256 b0 = Fr::add(a0, a1), b1 = Fr::sub(a0, a1);
+      u256 b2 = Fr::add(a2, a3), b3 = Fr::sub(a2, a3);
+      if (p) {
+        const u256 tb = twl[p << (sA + 1)];
+        b1 = Fr::mul(b1, tb);
+        b3 = Fr::mul(b3, tb);
+      }
+      lds[i0] = b0;
+      lds[i1] = b1;
+      lds[i2] = b2;
+      lds[i3] = b3;
     }
     __syncthreads();
   }

@@ -36,6 +36,21 @@ def load(path, counter):
     return agg
 
 
+def provenance():
+    """which build the counters belong to: bench.py only reports them next to a run of the SAME library"""
+    import hashlib
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256(open(os.path.join(root, "nim_groth16_amd", "csrc", "libg16hip.so"), "rb").read()).hexdigest()[:16]
+    try:
+        git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        git = None
+    return {"lib_sha16": h, "git": git, "box": os.environ.get("G16_BOX_NOTE", "one MI355X gpurun box; counters and "
+                                                                "kernel trace of one session")}
+
+
 def main():
     root, out = sys.argv[1], sys.argv[2]
     tag = sys.argv[3] if len(sys.argv) > 3 else "r01"          # the -o prefix given to rocprofv3
@@ -48,6 +63,7 @@ def main():
         kernels[k] = {"FETCH_SIZE_KB_avg_per_launch": round(fa, 1), "WRITE_SIZE_KB_avg_per_launch": round(wa, 1),
                       "launches": len(f.get(k) or w.get(k)), "hbm_bytes_per_launch_raw": int((fa + wa) * 1024)}
     doc = {
+        **provenance(),
         "workload": "bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline (2^20 full prove), rocprofv3 --pmc "
                     "FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
         "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch; hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024",

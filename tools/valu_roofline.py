@@ -127,9 +127,9 @@ def short(name):
     return base
 
 
-def pmc(root):
-    rows = list(csv.DictReader(open(os.path.join(root, "r02_counter_collection.csv"))))
-    kt = list(csv.DictReader(open(os.path.join(root, "r02_kernel_trace.csv"))))
+def pmc(root, tag="r02"):
+    rows = list(csv.DictReader(open(os.path.join(root, f"{tag}_counter_collection.csv"))))
+    kt = list(csv.DictReader(open(os.path.join(root, f"{tag}_kernel_trace.csv"))))
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in kt}
     per, names = collections.defaultdict(dict), {}
     for r in rows:
@@ -157,8 +157,9 @@ def pmc(root):
 
 def main():
     pmc_root, ubench_path, out_path = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "r02"          # the -o prefix given to rocprofv3
     tab = ubench_table(ubench_path)
-    counters = pmc(pmc_root)
+    counters = pmc(pmc_root, tag)
     csrc = os.path.join(ROOT, "nim_groth16_amd", "csrc")
     loops = {"msm_accum_g1": ("msm_g1_accum.o", r"msm_accum"), "msm_accum_g2": ("msm_g2_accum.o", r"msm_accum"),
              "ntt_pass": ("ntt.o", r"ntt_passILi"), "ntt_last_pass_abc": ("ntt.o", r"ntt_last_pass_abc")}
@@ -179,7 +180,10 @@ def main():
         t_mul = kernels[k]["mad_u64_wave_insts_per_launch"] / SIMDS * tab["v_mad_u64_u32"] / (c["sustained_clock_ghz"] * 1e9) * 1e6
         kernels[k]["bound_us_mix"], kernels[k]["frac_mix"] = round(t_mix, 1), round(t_mix / c["duration_us"], 4)
         kernels[k]["bound_us_multiply_only"], kernels[k]["frac_multiply_only"] = round(t_mul, 1), round(t_mul / c["duration_us"], 4)
-    doc = {"how": "tools/valu_roofline.py (recipe in its docstring): ubench issue costs in real cycles (s_memtime), static "
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pmc_traffic import provenance
+    doc = {**provenance(),
+           "how": "tools/valu_roofline.py (recipe in its docstring): ubench issue costs in real cycles (s_memtime), static "
                   "hot-loop mix from the built objects, dynamic VALU wave-instructions / duration / clock from one rocprofv3 "
                   "--pmc pass of tools/perf.py --only reg --log2n 20 (registered G1 / G2 MSM, NTT, quotient; each kernel alone on the GPU)",
            "issue_cycles": tab, "simds": SIMDS, "kernels": kernels,
