@@ -69,7 +69,7 @@ class ShardedProver:
 
     def __init__(self, zkey, rank: int, world: int, ctx=None, group=None,
                  partials_fn: Optional[Callable] = None, combine_fn: Optional[Callable] = None,
-                 quotient: str = "tasks", pkey=None, depth: int = 2):
+                 quotient: str = "tasks", pkey=None, depth: int = 2, ctx_factory: Optional[Callable] = None):
         import torch.distributed as dist
         self.dist, self.group, self.rank, self.world, self.zkey = dist, group, rank, world, zkey
         self.pkey = pkey                # an already loaded key of this rank's shard, or None: load it here
@@ -80,6 +80,7 @@ class ShardedProver:
         assert quotient in ("tasks", "replicated")
         self.task_quotient = quotient == "tasks" and self.pkey is not None and zkey.header.flavour == 1
         self.depth = max(1, depth)
+        self._ctx_factory = ctx_factory     # extra contexts of the pipeline (tests inject CPU stand-ins)
         self._slots = []
         self._head = 0                  # next slot to submit into
         self._inflight = []             # slots in submission order
@@ -93,6 +94,8 @@ class ShardedProver:
         while len(self._slots) <= i:
             if not self._slots:
                 s = _Slot(self.pkey.ctx, False)
+            elif self._ctx_factory is not None:
+                s = _Slot(self._ctx_factory(), True)
             else:
                 from ._lib import Context
                 s = _Slot(Context(self.pkey.ctx.device), True)
@@ -109,7 +112,7 @@ class ShardedProver:
         import torch
         if s.mine is not None:
             return
-        dev = f"cuda:{self.pkey.ctx.device}"
+        dev = "cpu" if self.pkey.ctx.device is None else f"cuda:{self.pkey.ctx.device}"   # None: CPU stand-in (tests)
         n = self.zkey.header.domainSize
         s.slot_bytes = 32 * max(1, max(hi - lo for lo, hi in self._ranges))   # scatter needs equal chunks: pad to the largest
         s.mine = torch.empty(PARTIALS_BYTES, dtype=torch.uint8, device=dev)
@@ -165,7 +168,7 @@ class ShardedProver:
                     for w in s.works:
                         w.wait()                 # stream-level wait under RCCL (the host does not block)
                     s.works = []
-                    if s.stream is None:         # slices are in HBM before the library's own stream reads them
+                    if s.stream is None and s.mine.is_cuda:   # slices are in HBM before the library's own stream reads them
                         torch.cuda.current_stream(s.mine.device).synchronize()
                     ptrs = [t.data_ptr() if nh else None for t in s.slices]
                 self.pkey.prove_partials_end(ptrs[0], ptrs[1], ptrs[2], out=s.mine.data_ptr(), ctx=s.ctx,

@@ -143,6 +143,8 @@ def pmc(root, tag="r02"):
     out = {}
     for k, lst in agg.items():
         lst.sort(key=lambda t: t[0])
+        med = lst[len(lst) // 2][0]
+        lst = [t for t in lst if t[0] >= 0.5 * med]      # drop toy-size launches (the known-answer MSM / NTT of g16_selftest)
         lst = lst[:max(1, len(lst) * 3 // 4)]            # drop the slowest quarter (first-touch / cold launches)
         n = len(lst)
         us = sum(t[0] for t in lst) / n / 1e3
