@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_step4_bench_2p20_final.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_2p20_final.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -23,19 +23,27 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("reference", "port")
     assert "witness from host" in d["config"]["inputs"] and d["keys_resident_per_gpu"] == 1
+    # round 3: the fraction comes from the UNCONTENDED launch, the contended figure is a named extra, and every
+    # counter-derived number names the build it was measured on -- the build of this very run
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert r["contended_launch_ms_in_timed_region"] > r["avg_launch_ms"]
+    assert r["inputs_from"]["lib_sha16"] == d["lib_sha16"] == d["roofline_valu"]["inputs_from"]["lib_sha16"]
+    v = d["roofline_valu"]
+    assert "g16_profile_clock" in v["clock_source"] and 1.5 < v["sustained_clock_ghz"] < 2.6 and 0.8 < v["frac_mix"] < 1.0
 
 
 def test_valu_roofline_inputs_are_consistent():
-    """profiles/r02_valu_roofline_inputs.json (tools/valu_roofline.py) -> bench.py's roofline_valu object"""
+    """profiles/r03_valu_roofline_inputs.json (tools/valu_roofline.py) -> bench.py's roofline_valu object"""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    inp = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_roofline_inputs.json")))
+    inp = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_roofline_inputs.json")))
+    assert inp["lib_sha16"] and inp["git"]
     k = inp["kernels"]["msm_accum_g1"]
     assert 0.5 < k["mad_u64_share_of_valu"] < 0.7 and 3.5 < k["mix_issue_cycles_per_inst"] < 4.5
     assert 4.0 < inp["issue_cycles"]["v_mad_u64_u32"] < 5.0 and 1.8 < k["sustained_clock_ghz"] < 2.5
     r = bench.valu_roofline("msm_accum_g1", k["duration_us"] / 1e3, k["sustained_clock_ghz"],
-                            {"valu": inp, "valu_from": {"file": "profiles/r02_valu_roofline_inputs.json"}})
+                            {"valu": inp, "valu_from": {"file": "profiles/r03_valu_roofline_inputs.json"}})
     for key in ("bound", "achieved_ms", "valu_wave_insts_per_launch", "sustained_clock_ghz", "bound_ms_mix", "frac_mix",
                 "bound_ms_multiply_only", "frac_multiply_only"):
         assert key in r, key
@@ -68,7 +76,8 @@ def test_accumulate_hot_loops_keep_their_instruction_budget():
     g1 = V.hot_loop_mix(V.code_object(os.path.join(csrc, "msm_g1_accum.o")), r"msm_accum")
     valu = sum(c for op, c in g1.items() if op.startswith("v_"))
     assert g1["v_mad_u64_u32"] == 6 * 162 + 2 * 126 + 243 == 1467
-    assert valu <= 2500, valu                                # 2422 when this was written
+    assert valu <= 2500, valu                                # 2431 when this was written
+    assert g1.get("s_nop", 0) <= 300, g1.get("s_nop")        # 249: column chains as asm statements (1261 with per-product pins)
     assert not any(op.startswith("scratch_store") for op in g1), "the G1 accumulate loop spills"
     g2 = V.hot_loop_mix(V.code_object(os.path.join(csrc, "msm_g2_accum.o")), r"msm_accum")
     assert 4300 <= g2["v_mad_u64_u32"] <= 4400 and sum(c for op, c in g2.items() if op.startswith("v_")) <= 6700
