@@ -87,14 +87,9 @@ def self_launch(args, argv):
 
 
 def lib_sha16():
-    """identity of the library build the static roofline inputs must belong to"""
-    import hashlib
-    from nim_groth16_amd._lib import lib_path
-    h = hashlib.sha256()
-    with open(lib_path(), "rb") as f:
-        for blk in iter(lambda: f.read(1 << 20), b""):
-            h.update(blk)
-    return h.hexdigest()[:16]
+    """identity of the kernels the static roofline inputs must belong to (nim_groth16_amd/_lib.py)"""
+    from nim_groth16_amd._lib import device_code_sha16
+    return device_code_sha16()
 
 
 def build_inputs(args, ctx, rank, world, dist):
@@ -106,7 +101,9 @@ def build_inputs(args, ctx, rank, world, dist):
     from nim_groth16_amd.synthetic import SplitMix64, squaringChain
     n = 1 << args.log2n
     m = n - 2
-    path = f"/dev/shm/g16bench_{os.environ.get('MASTER_PORT', '0')}_{args.log2n}.pkl"
+    import tempfile
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(shm, f"g16bench_{os.environ.get('MASTER_PORT', '0')}_{args.log2n}.pkl")
     if rank == 0:
         r1cs, wit0 = squaringChain(m, seed=4)
         # more satisfying witnesses of the SAME circuit: the chain constants k_i (which are what the key depends on)
@@ -389,8 +386,8 @@ def measure(args, rank, world, local, dist, coll_dev, state):
 
 def static_inputs(args, shard, dom):
     """Per-launch quantities that only a rocprofv3 counter pass can deliver (HBM bytes, VALU wave-instructions): read
-    from the committed files of THIS build -- every file names the library hash it was measured on, and anything
-    measured on another build is dropped (null) rather than reported as if it belonged to this run."""
+    from the committed files of THIS build -- every file names the hash of the device code (the .hip_fatbin section of
+    libg16hip.so) it was measured on, and anything measured on other kernels is dropped (null) rather than reported as if it belonged to this run."""
     out = {"traffic": None, "traffic_from": None, "valu": None, "valu_from": None}
     if args.log2n != 20 or shard:
         return out
@@ -400,15 +397,15 @@ def static_inputs(args, shard, dom):
             path = os.path.join(ROOT, "profiles", name)
             try:
                 d = json.load(open(path))
-                if d.get("lib_sha16") != sha:
-                    out[key + "_from"] = {"file": "profiles/" + name, "dropped": "measured on another build "
-                                          f"({d.get('lib_sha16')}, this run: {sha})"}
+                if d.get("kernels_sha16") != sha:
+                    out[key + "_from"] = {"file": "profiles/" + name, "dropped": "measured on other kernels "
+                                          f"({d.get('kernels_sha16')}, this run: {sha})"}
                     continue
                 if key == "traffic":
                     out["traffic"] = d["kernels"][dom]["hbm_bytes_per_launch_raw"]
                 else:
                     out["valu"] = d
-                out[key + "_from"] = {"file": "profiles/" + name, "lib_sha16": sha, "git": d.get("git"),
+                out[key + "_from"] = {"file": "profiles/" + name, "kernels_sha16": sha, "git": d.get("git"),
                                       "box": d.get("box")}
                 break
             except Exception:
@@ -468,7 +465,7 @@ def finish_rank0(args, world, st):
     extra["proof_latency_ms_single_in_flight"] = round(st["lat_ms"], 3)
     extra["proofs_in_flight_per_gpu"] = inflight
     extra["keys_resident_per_gpu"] = 1
-    extra["lib_sha16"] = lib_sha16()
+    extra["kernels_sha16"] = lib_sha16()
     out.update(extra)
     print(json.dumps(out), flush=True)
 

@@ -42,6 +42,9 @@ proc g16_ntt_fr(ctx: ptr G16Ctx, src, dst: pointer, log2n: uint32, inverse: int3
 proc g16_quotient(ctx: ptr G16Ctx, az, bz, cz: pointer, log2n, flavour: uint32, res: pointer): int32 {.importc, header: "g16hip.h".}
 proc g16_pkey_create(ctx: ptr G16Ctx, desc: ptr G16PKeyDesc, key: ptr ptr G16PKey): int32 {.importc, header: "g16hip.h".}
 proc g16_prove(ctx: ptr G16Ctx, key: ptr G16PKey, witness: pointer, flags: uint32, r, s: pointer, res: ptr G16Proof): int32 {.importc, header: "g16hip.h".}
+# points at infinity per ProverPoints array (A1, B1, B2, C1, H1, B1-and-B2) and whether A1 / B1+B2 run on compacted
+# entry lists: snarkjs keys hold (0,0) for every wire absent from a matrix (curves.nim:95-107 accepts them)
+proc g16_pkey_inf_counts(key: ptr G16PKey, res: ptr array[8, csize_t]): int32 {.importc, header: "g16hip.h".}
 
 var gctx: ptr G16Ctx
 

@@ -57,6 +57,35 @@ def lib_path() -> str:
     return os.environ.get("G16HIP_LIB", os.path.join(_HERE, "csrc", "libg16hip.so"))
 
 
+def device_code_sha16(path: str = None) -> str:
+    """Identity of the KERNELS of a libg16hip.so build: sha256 prefix of its .hip_fatbin section (the gfx950 code
+    objects).  Host-side edits of the library leave it unchanged; any kernel change alters it.  bench.py reports
+    counter-derived numbers (HBM traffic, VALU instruction counts) only next to files stamped with the same value."""
+    import hashlib
+    import struct
+    b = open(path or lib_path(), "rb").read()
+    h = hashlib.sha256()
+    try:
+        assert b[:4] == b"\x7fELF" and b[4] == 2
+        shoff = struct.unpack_from("<Q", b, 0x28)[0]
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+
+        def sh(i):
+            name, _typ, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", b, shoff + i * shentsize)
+            return name, off, size
+        _, stro, _ = sh(shstrndx)
+        hit = False
+        for i in range(shnum):
+            n, off, size = sh(i)
+            if b[stro + n: b.index(b"\0", stro + n)] == b".hip_fatbin":
+                h.update(b[off: off + size])
+                hit = True
+        assert hit
+    except Exception:
+        h = hashlib.sha256(b)             # not an ELF with a fat binary: the whole file
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

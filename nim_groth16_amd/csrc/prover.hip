@@ -127,8 +127,9 @@ extern "C" void g16_pkey_destroy(g16_pkey* k) {
 // out[5] = wires whose B1 and B2 points are both (0,0); out[6] = 1 if A1, out[7] = 1 if B1/B2 use compacted entry lists
 extern "C" int32_t g16_pkey_inf_counts(const g16_pkey* k, size_t out[8]) {
   if (!k || !out) return G16_EINVAL;
-  size_t pad = 0;
-  for (size_t wI = k->w_lo; wI < k->w_hi; ++wI) pad += wI <= k->npubs ? 1 : 0;
+  // public wires 0 .. npubs of this shard's wire range: their C1 slots are this library's padding, not key points
+  const size_t pub_end = std::min<size_t>(k->w_hi, (size_t)k->npubs + 1);
+  const size_t pad = pub_end > k->w_lo ? pub_end - k->w_lo : 0;
   out[0] = k->A1->n_inf, out[1] = k->B1->n_inf, out[2] = k->B2->n_inf, out[3] = k->C1->n_inf - pad, out[4] = k->H1->n_inf;
   out[5] = k->deadB, out[6] = k->liveA ? 1 : 0, out[7] = k->liveB ? 1 : 0;
   return G16_OK;

@@ -40,18 +40,20 @@ def load(path, counter):
 
 
 def provenance():
-    """which build the counters belong to: bench.py only reports them next to a run of the SAME library"""
-    import hashlib
+    """which kernels the counters belong to: bench.py only reports them next to a run of the SAME device code
+    (sha256 prefix of the .hip_fatbin section of libg16hip.so: host-side edits of the library do not change it)"""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256(open(os.path.join(root, "nim_groth16_amd", "csrc", "libg16hip.so"), "rb").read()).hexdigest()[:16]
+    sys.path.insert(0, root)
+    from nim_groth16_amd._lib import device_code_sha16
+    h = device_code_sha16(os.path.join(root, "nim_groth16_amd", "csrc", "libg16hip.so"))
     try:
         git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         git = None
-    return {"lib_sha16": h, "git": git, "box": os.environ.get("G16_BOX_NOTE", "one MI355X gpurun box; counters and "
-                                                                "kernel trace of one session")}
+    return {"kernels_sha16": h, "git": git, "box": os.environ.get("G16_BOX_NOTE", "one MI355X gpurun box; counters and "
+                                                                    "kernel trace of one session")}
 
 
 def main():
