@@ -187,8 +187,9 @@ static __global__ void __launch_bounds__(256) bucket_hist(const uint2* __restric
 // launches for -- the extra-segment bookkeeping of split buckets (xoff[], heavy list; split buckets are rare, so
 // their range of extra-segment slots comes from one global atomic each instead of a device-wide scan) and the size
 // histogram of the permutation (perm_hist).
-constexpr int PERM_BINS_ = 256;
-__device__ __forceinline__ uint32_t extra_segs_(uint32_t cnt, uint32_t L) { return cnt > L ? (cnt - 1) / L : 0u; }
+constexpr int PERM_BINS = 256;   // size classes of the bucket-order permutation (perm_hist / perm_scatter below)
+// extra segments of a bucket of cnt entries cut into segments of L: max(ceil(cnt / L) - 1, 0)
+__device__ __forceinline__ uint32_t extra_segs(uint32_t cnt, uint32_t L) { return cnt > L ? (cnt - 1) / L : 0u; }
 static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restrict__ tmp,
                                                            const uint32_t* __restrict__ part_base, uint32_t ntiles,
                                                            uint32_t nparts, const uint32_t* __restrict__ total,
@@ -200,7 +201,7 @@ static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restri
                                                            uint32_t* __restrict__ info, uint32_t* __restrict__ ghist,
                                                            uint32_t* __restrict__ blk_base) {
   __shared__ uint32_t cur[256];
-  __shared__ uint32_t szh[PERM_BINS_];
+  __shared__ uint32_t szh[PERM_BINS];
   const uint32_t part = blockIdx.x / BS_SPLIT, q = blockIdx.x % BS_SPLIT, tid = threadIdx.x;
   const uint32_t start = part_base[(size_t)part * ntiles];
   const uint32_t end = part + 1 < nparts ? part_base[(size_t)(part + 1) * ntiles] : total[0];
@@ -232,14 +233,14 @@ static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restri
       count[b] = mine;
       offset[b] = start + excl;
       if (fused) {
-        const uint32_t e = extra_segs_(mine, P.seg);
+        const uint32_t e = extra_segs(mine, P.seg);
         uint32_t x0 = 0;
         if (e) {
           x0 = atomicAdd(&info[1], e);
           heavy[atomicAdd(&info[2], 1u)] = b;
         }
         xoff[b] = x0;
-        atomicAdd(&szh[mine < PERM_BINS_ - 1 ? mine : PERM_BINS_ - 1], 1u);
+        atomicAdd(&szh[mine < PERM_BINS - 1 ? mine : PERM_BINS - 1], 1u);
       }
     }
     if (part == nparts - 1 && tid == 0) offset[P.nbuckets] = end;
@@ -247,7 +248,7 @@ static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restri
   __syncthreads();
   if (q == 0 && fused) {
     const uint32_t m = szh[tid];
-    blk_base[(size_t)part * PERM_BINS_ + tid] = m ? atomicAdd(&ghist[tid], m) : 0u;
+    blk_base[(size_t)part * PERM_BINS + tid] = m ? atomicAdd(&ghist[tid], m) : 0u;
   }
   uint32_t lo, hi;
   bs_slice(start, end, q, lo, hi);
@@ -266,7 +267,6 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_ITEMS = 8;                       // per thread
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;  // 2048 buckets per workgroup
 
-__device__ __forceinline__ uint32_t extra_segs(uint32_t cnt, uint32_t L) { return cnt > L ? (cnt - 1) / L : 0u; }
 // split buckets with at least this many extra segments are combined by a workgroup (msm_heavy), the others by
 // one thread each (msm_heavy_small)
 constexpr uint32_t HEAVY_MIN = 12;
@@ -413,7 +413,6 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_make_extra(const uint32_
 // lanes of a wave get (nearly) equal trip counts.  Two small kernels: per-block LDS histogram + one global
 // atomic per (block, size class) to reserve a range, then ranks from LDS atomics.
 constexpr int PERM_BLOCK = 256;
-constexpr int PERM_BINS = 256;
 static __global__ void __launch_bounds__(PERM_BLOCK) perm_hist(const uint32_t* __restrict__ count, uint32_t nb,
                                                                uint32_t* __restrict__ ghist,
                                                                uint32_t* __restrict__ blk_base) {
