@@ -58,6 +58,12 @@ def test_field_formulas(shim):
             assert f(8, a) == a * Ri % mod and f(9, a) == a * Rm % mod
         a = rng.randrange(1, mod)
         assert f(7, a * Rm % mod) == pow(a, -1, mod) * Rm % mod and f(7, 0) == 0
+        # the division-step inversion (ff.cuh: 30 steps per batch on signed 30-bit limbs): edge values whose limb
+        # patterns stress the sign handling and the early exits, then random ones
+        edge = [1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, (mod - 1) // 2, 1 << 30, (1 << 30) - 1, 1 << 60, (1 << 240) + 1,
+                (1 << 253) % mod, Rm, Ri, mod // 3, 0x3fffffff << 30, (1 << 128) - 1, 5 ** 100 % mod]
+        for a in edge + [rng.randrange(1, mod) for _ in range(400)]:
+            assert f(7, a) == pow(a * Ri % mod, -1, mod) * Rm % mod, hex(a)
 
 
 def test_fp2_formulas(shim):

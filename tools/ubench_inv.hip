@@ -1,8 +1,9 @@
 // Micro-benchmark for the batched-affine question: what does ONE field
 // inversion cost a wave, in units of the 9x29 multiplication the accumulate kernels are built from?
-// Every lane inverts its own (different) value with the library's binary extended Euclid (Fp::inv, ff.cuh) --
-// data-dependent, so the 64 lanes of a wave diverge and the wave pays for the slowest path of every step -- and,
-// for comparison, runs a dependent chain of Fp29::mul.  Batched-affine bucket accumulation replaces the mixed
+// Every lane inverts its own (different) value -- data-dependent, so the 64 lanes of a wave diverge and the wave pays
+// for the slowest path of every step -- with (a) the binary extended Euclid of rounds 1-2 (Fp::inv_eea) and (b) the
+// batched division-step inversion of round 3 (Fp::inv, ff.cuh), and, for comparison, runs a dependent chain of
+// Fp29::mul.  Batched-affine bucket accumulation replaces the mixed
 // XYZZ addition (6M + 2S + one 2-term dot) by the affine one (5M + 1S incl. Montgomery's trick) PLUS 1/K of an
 // inversion per addition, K = additions sharing one inversion; this prints the K at which that breaks even.
 //   hipcc -O3 --offload-arch=gfx950 tools/ubench_inv.hip -o tools/ubench_inv && ./tools/ubench_inv
@@ -17,12 +18,18 @@ using namespace g16;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-template <int WAVES>
+template <int WAVES, bool EEA>
 __global__ void __launch_bounds__(256, WAVES) k_inv(u256* io, int iters) {
   u256 x = io[(blockIdx.x * 256 + threadIdx.x) & 4095];
   const u256 c = io[(threadIdx.x * 7 + 1) & 4095];
-  for (int i = 0; i < iters; ++i) x = Fp::add(Fp::inv(x), c);     // dependent chain, lane-varying values
+  for (int i = 0; i < iters; ++i) x = Fp::add(EEA ? Fp::inv_eea(x) : Fp::inv(x), c);   // dependent chain, lane-varying values
   if (x.v[0] == 0x12345u && x.v[1] == 0x77u) io[0] = x;
+}
+// correctness on the device: x * inv(x) == 1 and both algorithms agree
+__global__ void k_check(const u256* io, unsigned* bad) {
+  const u256 x = io[blockIdx.x * 64 + threadIdx.x];
+  const u256 a = Fp::inv(x), b = Fp::inv_eea(x);
+  if (!Fp::eq(a, b) || !Fp::eq(Fp::mul(x, a), Fp::one())) atomicAdd(bad, 1u);
 }
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_mul29(fe29* io, int iters) {
@@ -61,21 +68,33 @@ int main() {
   fe29* d29;
   CHECK(hipMalloc(&d29, 128 * sizeof(fe29)));
   CHECK(hipMemset(d29, 0x11, 128 * sizeof(fe29)));
+  unsigned* d_bad;
+  CHECK(hipMalloc(&d_bad, 4));
+  CHECK(hipMemset(d_bad, 0, 4));
+  hipLaunchKernelGGL(k_check, dim3(64), dim3(64), 0, 0, d, d_bad);
+  unsigned bad = 1;
+  CHECK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+  printf("4096 values: inv(x) == inv_eea(x) and x * inv(x) == 1 on the device: %s\n", bad ? "FAILED" : "ok");
+  if (bad) return 1;
   const int blocks = 4096;
   for (int waves : {2, 4}) {
     const int it_inv = 8, it_mul = 512;
-    double t_inv = waves == 2 ? time_ms([&] { hipLaunchKernelGGL(k_inv<2>, dim3(blocks), dim3(256), 0, 0, d, it_inv); })
-                              : time_ms([&] { hipLaunchKernelGGL(k_inv<4>, dim3(blocks), dim3(256), 0, 0, d, it_inv); });
+    double t_eea = waves == 2 ? time_ms([&] { hipLaunchKernelGGL((k_inv<2, true>), dim3(blocks), dim3(256), 0, 0, d, it_inv); })
+                              : time_ms([&] { hipLaunchKernelGGL((k_inv<4, true>), dim3(blocks), dim3(256), 0, 0, d, it_inv); });
+    double t_new = waves == 2 ? time_ms([&] { hipLaunchKernelGGL((k_inv<2, false>), dim3(blocks), dim3(256), 0, 0, d, it_inv); })
+                              : time_ms([&] { hipLaunchKernelGGL((k_inv<4, false>), dim3(blocks), dim3(256), 0, 0, d, it_inv); });
     double t_mul = waves == 2 ? time_ms([&] { hipLaunchKernelGGL(k_mul29<2>, dim3(blocks), dim3(256), 0, 0, d29, it_mul); })
                               : time_ms([&] { hipLaunchKernelGGL(k_mul29<4>, dim3(blocks), dim3(256), 0, 0, d29, it_mul); });
-    const double per_inv = t_inv / it_inv, per_mul = t_mul / (2.0 * it_mul);
-    const double ratio = per_inv / per_mul;
-    // mixed XYZZ addition ~ 9.06 M (1468 multiply-adds / 162); affine with Montgomery's trick 5M + 1S ~ 5.78 M
-    const double breakeven = ratio / (9.06 - 5.78);
-    printf("%d waves/SIMD, %d workgroups x 256 lanes: %.3f ms per inversion step, %.4f ms per multiplication step => one "
-           "inversion = %.1f multiplications of wave time; batched affine (5.78 M + inv/K) beats XYZZ (9.06 M) only for "
-           "K > %.1f additions per inversion; at K = 16: %.2f M, K = 32: %.2f M, K = 64: %.2f M per addition\n",
-           waves, blocks, per_inv, per_mul, ratio, breakeven, 5.78 + ratio / 16, 5.78 + ratio / 32, 5.78 + ratio / 64);
+    const double per_mul = t_mul / (2.0 * it_mul);
+    for (int alg = 0; alg < 2; ++alg) {
+      const double per_inv = (alg ? t_new : t_eea) / it_inv, ratio = per_inv / per_mul;
+      // mixed XYZZ addition ~ 9.06 M (1468 multiply-adds / 162); affine with Montgomery's trick 5M + 1S ~ 5.78 M
+      printf("%d waves/SIMD, %s: %.3f ms per inversion step, %.4f ms per multiplication step => one inversion = %.1f "
+             "multiplications of wave time; batched affine (5.78 M + inv/K) beats XYZZ (9.06 M) only for K > %.1f additions "
+             "per inversion; at K = 16: %.2f M, K = 32: %.2f M, K = 64: %.2f M per addition\n",
+             waves, alg ? "division steps (Fp::inv)    " : "binary Euclid (Fp::inv_eea)", per_inv, per_mul, ratio,
+             ratio / (9.06 - 5.78), 5.78 + ratio / 16, 5.78 + ratio / 32, 5.78 + ratio / 64);
+    }
   }
   return 0;
 }
