@@ -31,6 +31,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the 18 streams of three in-flight
+# proofs do measurably better on 8 (same-box A/B, profiles/r03_ab_hwqueues.txt: 114.8 -> 116.4 proofs/s; 6 and 16 are
+# worse).  Read by the HIP runtime when it initialises, so it is set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 NWITNESS = 3          # distinct satisfying witnesses the timed steps rotate over (w_0 = 3, 5, 7; same k_i, same key)
 
