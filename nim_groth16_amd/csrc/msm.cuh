@@ -4,13 +4,14 @@
 // same canonical affine output.
 //
 // Pipeline (one stream, no host round trip inside):
-//   K1 msm_count     scalar -> signed c-bit digits; histogram of (window,|digit|) buckets   [HBM: 32 B/scalar]
-//   K2 scan3         exclusive scans: bucket offsets + extra-segment offsets + heavy list
-//   K3 msm_scatter   recompute digits, write (point index | sign) into its bucket's slot
-//   K4 msm_accum     one thread per bucket *segment* (<= L entries): XYZZ += affine (8M+2S each)
-//   K5 msm_heavy     one workgroup per bucket that was split in >1 segment: LDS tree of partials
-//   K6 msm_reduce1/2 sum_k k*B_k per window: chunked running sums, then LDS suffix-scan per window
-//   K7 msm_fold      sum_w 2^(cw) S_w (or plain sum for precomputed tables) + one inversion -> affine
+//   sort   part_pass<false/true>, scan1_*, bucket_hist, bucket_place, perm_scatter, msm_make_extra
+//          scalar -> signed c-bit digits; two-level LDS partition sort of the (bucket, point index | sign) entries; bucket
+//          offsets, split-bucket segment list, buckets ordered by size.  (msm_count / msm_scatter / scan_* / perm_hist:
+//          the global-atomic variant, used when the partition count exceeds the LDS histogram and by G16_MSM_SORT=a)
+//   accum  msm_accum      one thread per bucket *segment* (<= L entries): XYZZ += affine table point, 9x29 field
+//   heavy  msm_heavy[_small]  buckets that were split in >1 segment: LDS tree / one thread
+//   reduce msm_reduce1/2  sum_k k*B_k: 16-bucket chunk running sums, then per slice an LDS suffix scan + tree
+//   fold   msm_fold[_merged]  slices (registered sets) or windows (Horner) -> one point; canonical affine on request
 //
 // Load balance: work is cut by *entries*, not by buckets -- a circom witness puts ~30 % of all
 // scalars in bucket (w=0, d=1); that bucket becomes ~N/L segments handled by N/L threads.
