@@ -47,8 +47,9 @@ def log(*a):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=288,
+                    help="timed proofs (default 288: a ~2.5-s timed region at 2^20; round 2's 96 steps = 0.9 s were within box noise)")
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--log2n", type=int, default=20, help="domain size 2^log2n (constraints m = 2^log2n - 2)")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
