@@ -109,6 +109,36 @@ static DevAff host_add(const DevAff& a_dev, const DevAff& b_dev) {
   memcpy(&out, &r, sizeof out);
   return out;
 }
+// k1 * p1 + k2 * p2 with ONE doubling chain (Shamir's trick, 2-bit joint windows: 16-entry table i*p1 + j*p2):
+// 254 doublings + <= 127 additions instead of two separate 4-bit-window multiplications (512 + 156)
+template <class HC, class DevAff>
+static DevAff host_mul2(const u256& k1_std, const DevAff& p1_dev, const u256& k2_std, const DevAff& p2_dev) {
+  typename HC::Aff p1, p2;
+  memcpy(&p1, &p1_dev, sizeof p1);
+  memcpy(&p2, &p2_dev, sizeof p2);
+  typename HC::Acc tab[16];   // tab[4 i + j] = i*p1 + j*p2
+  tab[0] = HC::acc_inf();
+  for (int j = 1; j < 4; ++j) {
+    tab[j] = tab[j - 1];
+    HC::madd(tab[j], p2);
+  }
+  for (int i = 1; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      tab[4 * i + j] = tab[4 * (i - 1) + j];
+      HC::madd(tab[4 * i + j], p1);
+    }
+  typename HC::Acc acc = HC::acc_inf();
+  for (int limb = 7; limb >= 0; --limb)
+    for (int pos = 15; pos >= 0; --pos) {
+      if (!HC::is_inf(acc)) acc = HC::dbl(HC::dbl(acc));
+      const uint32_t w = 4 * ((k1_std.v[limb] >> (2 * pos)) & 3u) + ((k2_std.v[limb] >> (2 * pos)) & 3u);
+      if (w) HC::add(acc, tab[w]);
+    }
+  typename HC::Aff r = HC::to_affine(acc);
+  DevAff out;
+  memcpy(&out, &r, sizeof out);
+  return out;
+}
 
 extern "C" void g16_pkey_destroy(g16_pkey* k) {
   if (!k) return;
@@ -570,27 +600,29 @@ extern "C" int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* k, const void
     g1_aff h, c;
   } res;
   static_assert(sizeof(res) == 384, "slot layout");
-  HIPCHK(ctx, hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
 
-  // mask scalars -> standard form and the delta multiples while the GPU works (prover.nim:267-268)
+  // Everything that depends on the mask and the key alone is computed while the GPU works -- in g16_prove that is the
+  // whole proof, which is enqueued without a host wait (prover.nim:267-268, 279-302 regrouped):
+  //   pi_a = (alpha1 + r delta1) + A                      pi_b = (beta2 + s delta2) + B2
+  //   pi_c = s pi_a + r rho - rs delta1 + H + C           with rho = beta1 + s delta1 + B1
+  //        = (s alpha1 + r beta1 + rs delta1) + (s A + r B1) + H + C
+  // The same group elements as the reference's order of operations, hence the same canonical affine bytes.
   u256 r = Fr::zero(), s = Fr::zero();
   if (mask_r) memcpy(&r, mask_r, 32);
   if (mask_s) memcpy(&s, mask_s, 32);
   const u256 r_std = Fr::from_mont(r), s_std = Fr::from_mont(s);
-  const u256 mrs_std = Fr::from_mont(Fr::neg(Fr::mul(r, s)));
-  const g1_aff r_delta1 = host_mul<HG1>(r_std, k->delta1);
-  const g1_aff s_delta1 = host_mul<HG1>(s_std, k->delta1);
-  const g2_aff s_delta2 = host_mul<HG2>(s_std, k->delta2);
-  const g1_aff mrs_delta1 = host_mul<HG1>(mrs_std, k->delta1);
+  const u256 rs_std = Fr::from_mont(Fr::mul(r, s));
+  const g1_aff a_pre = host_add<HG1>(k->alpha1, host_mul<HG1>(r_std, k->delta1));
+  const g2_aff b_pre = host_add<HG2>(k->beta2, host_mul<HG2>(s_std, k->delta2));
+  const g1_aff c_pre = host_add<HG1>(host_mul2<HG1>(s_std, k->alpha1, r_std, k->beta1), host_mul<HG1>(rs_std, k->delta1));
+  // (the copy into pageable host memory makes the host wait for the stream: it comes AFTER the host arithmetic above)
+  HIPCHK(ctx, hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 
-  // prover.nim:279-302
-  g1_aff pi_a = host_add<HG1>(host_add<HG1>(k->alpha1, r_delta1), res.a);
-  g1_aff rho = host_add<HG1>(host_add<HG1>(k->beta1, s_delta1), res.b1);
-  g2_aff pi_b = host_add<HG2>(host_add<HG2>(k->beta2, s_delta2), res.b2);
-  g1_aff pi_c = host_mul<HG1>(s_std, pi_a);
-  pi_c = host_add<HG1>(pi_c, host_mul<HG1>(r_std, rho));
-  pi_c = host_add<HG1>(pi_c, mrs_delta1);
+  // what needs the MSM results: three additions and ONE joint double-scalar multiplication
+  g1_aff pi_a = host_add<HG1>(a_pre, res.a);
+  g2_aff pi_b = host_add<HG2>(b_pre, res.b2);
+  g1_aff pi_c = host_add<HG1>(c_pre, host_mul2<HG1>(s_std, res.a, r_std, res.b1));
   pi_c = host_add<HG1>(pi_c, res.h);
   pi_c = host_add<HG1>(pi_c, res.c);
   memcpy(out->pi_a, &pi_a, 64);
@@ -616,8 +648,12 @@ extern "C" int32_t g16_prove(g16_ctx* ctx, const g16_pkey* k, const void* witnes
   if ((rc = ensure(ctx, ctx->stage_s, PART_BYTES))) return rc;
   // partials stay in HBM (stage_s is free again once the witness has been copied into the prove buffer)
   unsigned char* d_part = (unsigned char*)ctx->stage_s.p;
-  if ((rc = g16_prove_partials(ctx, k, witness, flags | G16_OUT_DEVICE, d_part))) return rc;
-  return g16_prove_combine(ctx, k, d_part, 1, G16_SCALARS_DEVICE, mask_r, mask_s, out);
+  // no host wait here: the combine's copy and kernel are ordered behind the record on the main stream, and its
+  // mask-only host arithmetic (~0.3 ms) then overlaps the whole proof instead of following it
+  if ((rc = g16_prove_partials(ctx, k, witness, flags | G16_OUT_DEVICE | G16_NO_HOST_SYNC, d_part))) return rc;
+  rc = g16_prove_combine(ctx, k, d_part, 1, G16_SCALARS_DEVICE, mask_r, mask_s, out);
+  if (rc != G16_OK) ctx_quiesce(ctx);   // a failed combine may leave the lanes running
+  return rc;
 }
 
 // quotient alone, host pointers (replaces computeSnarkjsScalarCoeffs / computeQuotientPointwise)
