@@ -31,6 +31,9 @@ struct G16Env {
   // launch order of a proof (experiments; the defaults are the measured optimum, tools/ab_schedule.sh):
   int quotient_first = 0;         // G16_QUOTIENT_FIRST=1: enqueue buildABC + quotient + sort(qs) before the witness MSMs
   int lanes_after_quotient = 0;   // G16_LANES_AFTER_QUOTIENT=1 (with the above): the witness accumulations wait for them
+  int g1_batch = 0;               // G16_G1_BATCH=1: ONE batched launch sequence (blockIdx.y = MSM) for A1, B1, C1 on one stream
+                                  // instead of one stream and one sequence per G1 MSM (prover.hip; measured slower)
+  int chain_ch = 1;               // G16_CHAIN_CH=0: C1 and H1 as two MSMs instead of H1 continuing C1's bucket sums
 };
 const G16Env& g16_env();
 
@@ -71,7 +74,7 @@ struct g16_ctx {
   };
   MsmSort sort[4];   // 0: witness (all pairs)  1: H scalars  2: witness, A1's live pairs  3: witness, B1/B2's live pairs
   MsmLane lane[5];
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_q = nullptr, ev_b2 = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_q = nullptr, ev_b2 = nullptr, ev_c = nullptr;
   Buf stage_s;   // staged scalars (host-pointer API)
   Buf stage_p;   // staged points
   Buf stage_p29; // the same points as reduced-radix entries (one-shot MSMs; registered sets keep their own tables)
@@ -204,20 +207,36 @@ const uint32_t* g16_points_live_if_sparse(const g16_points* p);
 // d_live (optional): bitmap over the n pairs; pairs with a cleared bit get no entries (point sets with (0,0) points)
 int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, uint32_t flags, size_t n,
                      uint32_t table_c, g16_ctx::MsmSort& sort, const uint32_t* d_live = nullptr);
+// Several MSMs of one group as ONE launch sequence on one stream (every stage kernel takes blockIdx.y = job): the jobs
+// must share the launch parameters (same n, same window: e.g. the G1 MSMs of a proof that consume the witness).
+//   n_accum jobs are accumulated (+ split buckets combined); the first n_tail <= n_accum of them are reduced and folded
+//   init_partial: the bucket sums (after `after_heavy`) of another job over the same bucket set, to continue from
+//   after_heavy (optional): recorded on the stream once every job's bucket sums are final
+struct g16_msm_run {
+  const g16_ctx::MsmSort* sort;
+  g16_ctx::Buf* acc;            // workspace of this job (bucket sums first: see g16_msm_partial_ptr)
+  const void* d_points;
+  void* d_out_aff;              // either may be null
+  void* d_out_acc;
+  const void* init_partial;
+};
+int32_t g16_msm_batch(g16_ctx* ctx, hipStream_t stream, int group, const g16_msm_run* runs, int n_accum, int n_tail,
+                      hipEvent_t after_heavy);
+inline const void* g16_msm_partial_ptr(const g16_ctx::Buf& acc) { return acc.p; }
 int32_t g16_msm_reduce_g1(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
                           const void* d_points, void* d_out_aff, void* d_out_acc);
 int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
                           const void* d_points, void* d_out_aff, void* d_out_acc);
 int32_t g16_lanes_init(g16_ctx* ctx);
 int g16_stream_priority(int index);
-// per-curve stages of phase 2, each compiled in its own translation unit (msm_g{1,2}_{accum,reduce1,reduce2}.hip)
-#define G16_DECL_STAGES(g)                                                                                              \
-  int32_t g16_st_accum_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, const void* points, void* partial);          \
-  int32_t g16_st_heavy_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, void* partial);                              \
-  int32_t g16_st_reduce1_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, const void* partial, void* chunkR,         \
-                             void* chunkA);                                                                             \
-  int32_t g16_st_reduce2_##g(g16_ctx*, hipStream_t, const g16_ctx::MsmSort&, const void* chunkR, const void* chunkA,    \
-                             void* wsum, void* out_aff, void* out_acc);
+// per-curve stages of phase 2, each compiled in its own translation unit (msm_g{1,2}_{accum,reduce1,reduce2}.hip).
+// `batch`: a g16::MsmBatch<G1 / G2> (msm.cuh) of `ny` jobs that share the launch parameters P.
+#define G16_DECL_STAGES(g)                                                                                            \
+  int32_t g16_st_accum_##g(g16_ctx*, hipStream_t, const g16::MsmParams& P, const void* batch, uint32_t ny);           \
+  int32_t g16_st_heavy_##g(g16_ctx*, hipStream_t, const g16::MsmParams& P, const void* batch, uint32_t ny);           \
+  int32_t g16_st_reduce1_##g(g16_ctx*, hipStream_t, const g16::MsmParams& P, const void* batch, uint32_t ny);         \
+  int32_t g16_st_reduce2_##g(g16_ctx*, hipStream_t, const g16::MsmParams& P, bool narrow_tail, const void* batch,     \
+                             uint32_t ny);
 G16_DECL_STAGES(g1)
 G16_DECL_STAGES(g2)
 int32_t g16_to29_device_g1(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out);

@@ -22,6 +22,8 @@ static G16Env read_env() {
   if (const char* v = getenv("G16_R2_WIDTH")) e.r2_width = v[0] == '0' ? 0 : v[0] == '2' ? 2 : 1;
   if (const char* v = getenv("G16_LANES_AFTER_QUOTIENT")) e.lanes_after_quotient = v[0] != '0';
   if (const char* v = getenv("G16_QUOTIENT_FIRST")) e.quotient_first = v[0] != '0';
+  if (const char* v = getenv("G16_G1_BATCH")) e.g1_batch = v[0] != '0';
+  if (const char* v = getenv("G16_CHAIN_CH")) e.chain_ch = v[0] != '0';
   if (const char* v = getenv("G16_NTT_TILE")) e.ntt_tile = atoi(v) == 1024 ? 1024 : atoi(v) == 4096 ? 4096 : 2048;
   if (const char* v = getenv("G16_MSM_SORT")) e.msm_sort = v[0];
   if (const char* v = getenv("G16_G1_LANES"))
@@ -88,6 +90,7 @@ int32_t g16_lanes_init(g16_ctx* ctx) {
   if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   if (hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   if (hipEventCreateWithFlags(&ctx->ev_b2, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
+  if (hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   return G16_OK;
 }
 
@@ -106,6 +109,7 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->ev_q) (void)hipEventDestroy(ctx->ev_q);
   if (ctx->ev_b2) (void)hipEventDestroy(ctx->ev_b2);
+  if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   for (g16_ctx::Buf* b : {&ctx->stage_s, &ctx->stage_p, &ctx->stage_p29, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
                           &ctx->coset[0], &ctx->coset[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
                           &ctx->fb_table[1]})

@@ -31,6 +31,63 @@ constexpr int ACC_BLOCK = G16_ACC_BLOCK;   // workgroup size of the accumulate k
 #endif
 constexpr int FR_BITS = 254;
 
+// Wave priority of the latency-bound kernels (split-bucket combine, reduce, fold; the sort): their few waves share the
+// SIMDs with the register-filling accumulate waves of the other streams, and every instruction they wait for the
+// arbiter lengthens a dependency chain the proof's end waits for.  s_setprio 3 = issue before priority-0 waves.
+#ifndef G16_TAIL_PRIO
+#define G16_TAIL_PRIO 0
+#endif
+__device__ __forceinline__ void tail_prio() {
+#if G16_TAIL_PRIO
+  __builtin_amdgcn_s_setprio(G16_TAIL_PRIO);
+#endif
+}
+#ifndef G16_G1_WAVES
+#define G16_G1_WAVES 4
+#endif
+// Register budget of the latency-bound kernels, as waves per SIMD they must allow (1 = whatever the compiler takes).
+// A wave can only start on a SIMD with that many free registers: while the accumulate kernels of other streams keep
+// refilling the SIMDs with 117-register (G1) / 241-register (G2) waves, a 481-register reduce1<G2> wave finds room
+// only when a whole SIMD drains -- the tails of a proof then wait for the accumulate launches to END instead of
+// slotting in behind single exiting waves.
+#ifndef G16_TAIL_WAVES_G1
+#define G16_TAIL_WAVES_G1 1
+#endif
+#ifndef G16_TAIL_WAVES_G2
+#define G16_TAIL_WAVES_G2 1
+#endif
+template <class C>
+constexpr int tail_waves() { return sizeof(typename C::Aff) == 64 ? G16_TAIL_WAVES_G1 : G16_TAIL_WAVES_G2; }
+
+// ---- batched launches -------------------------------------------------------------------------------------------
+// Every stage kernel from the accumulation to the fold takes up to MSM_BATCH_MAX independent MSMs per launch
+// (blockIdx.y = job).  The three G1 MSMs of a proof that consume the witness (A1, B1, C1: prover.nim:282-302) run as
+// ONE launch sequence on ONE stream: their latency-bound reduce / fold chains run three wide, a proof needs ~15
+// launches and 2 streams less, and the in-flight proofs of a GPU fit the hardware queues without sharing them.
+constexpr int MSM_BATCH_MAX = 3;
+template <class C>
+struct MsmJob {
+  const typename Ec29<C>::Tab* points;   // window tables (registered set) or reduced-radix entries (one-shot)
+  const uint32_t* entries;               // the bucket arrangement it runs against (g16_ctx::MsmSort)
+  const uint32_t* offset;
+  const uint2* xseg;
+  const uint32_t* info;
+  const uint32_t* perm;
+  const uint32_t* heavy;
+  const uint32_t* xoff;
+  typename Ec29<C>::Acc* partial;        // bucket / segment sums (reduced radix)
+  const typename Ec29<C>::Acc* init;     // optional: bucket sums of another MSM over the same bucket set to start from
+  typename C::Acc* chunkR;               // reduce1 -> reduce2
+  typename C::Acc* chunkA;
+  typename C::Acc* wsum;                 // reduce2 -> fold (2 * 64 + 2 accumulators)
+  typename C::Aff* out_aff;              // either may be null
+  typename C::Acc* out_acc;
+};
+template <class C>
+struct MsmBatch {
+  MsmJob<C> job[MSM_BATCH_MAX];
+};
+
 
 // signed c-bit digits of a scalar, least significant window first.  The canonical scalar stays in its 8 registers
 // and is shifted right by c bits per window (8 funnel shifts with static register indices, c <= 22 < 32): no LDS
@@ -468,12 +525,13 @@ static __global__ void __launch_bounds__(PERM_BLOCK) perm_scatter(const uint32_t
 // occupancy target: G1 fits 4 waves/SIMD (<=128 VGPRs); G2 is bounded to 256 registers (2 waves/SIMD;
 // 3 waves/SIMD with spills measured slower: 3.88 ms vs 3.52 ms on the 8x32 kernel)
 template <class C>
-__global__ void __launch_bounds__(ACC_BLOCK, sizeof(typename C::Aff) == 64 ? 4 : G16_G2_WAVES)
-msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __restrict__ entries,
-          const uint32_t* __restrict__ offset, const uint2* __restrict__ xseg, const uint32_t* __restrict__ info,
-          const uint32_t* __restrict__ perm, MsmParams P, typename Ec29<C>::Acc* __restrict__ partial,
-          unsigned long long* __restrict__ clk) {
+__global__ void __launch_bounds__(ACC_BLOCK, sizeof(typename C::Aff) == 64 ? G16_G1_WAVES : G16_G2_WAVES)
+msm_accum(const MsmBatch<C> B, MsmParams P, unsigned long long* __restrict__ clk) {
   using E = Ec29<C>;
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const typename E::Tab* __restrict__ points = J.points;
+  const uint32_t* __restrict__ entries = J.entries;
+  const uint32_t* __restrict__ offset = J.offset;
   // profiling only: shader-clock and 100 MHz stamps around thread 0's task (g16_profile_clock)
   unsigned long long t0 = 0, r0 = 0;
   const bool stamp = clk != nullptr && threadIdx.x == 0;
@@ -481,28 +539,31 @@ msm_accum(const typename Ec29<C>::Tab* __restrict__ points, const uint32_t* __re
   // task order = dispatch order: the extra segments of split buckets (the longest tasks, L entries each)
   // first, then the buckets by descending size, so that no long task is left for the tail of the launch
   const uint32_t t = blockIdx.x * ACC_BLOCK + threadIdx.x;
-  const uint32_t nx = info[1] < P.max_extra ? info[1] : P.max_extra;
+  const uint32_t nx = J.info[1] < P.max_extra ? J.info[1] : P.max_extra;
   uint32_t b, s, slot;
   if (t < nx) {
-    uint2 d = xseg[t];
+    uint2 d = J.xseg[t];
     b = d.x;
     s = d.y;
     slot = P.nbuckets + t;
   } else {
     if (t - nx >= P.nbuckets) return;
-    b = perm[t - nx];   // equal trip counts inside a wave
+    b = J.perm[t - nx];   // equal trip counts inside a wave
     s = 0;
     slot = b;
   }
   uint32_t beg = offset[b], end = offset[b + 1];
   beg += s * P.seg;
   if (end > beg + P.seg) end = beg + P.seg;
+  // `init`: this MSM continues the bucket sums of another one over the same bucket set (C1 -> H1 of a proof: only
+  // their sum enters pi_c, prover.nim:301-302, so the pair needs ONE bucket reduction)
   typename E::Acc acc = E::acc_inf();
+  if (J.init != nullptr && s == 0) acc = J.init[b];
   for (uint32_t j = beg; j < end; ++j) {
     const uint32_t e = entries[j];   // point index (table-major) | sign in bit 31
     E::madd(acc, points + (e & 0x7fffffffu), e >> 31);
   }
-  partial[slot] = acc;   // stays in the reduced-radix form: msm_heavy / msm_reduce1 consume it as is
+  J.partial[slot] = acc;   // stays in the reduced-radix form: msm_heavy / msm_reduce1 consume it as is
   if (stamp) {
     atomicAdd(&clk[0], __builtin_amdgcn_s_memtime() - t0);
     atomicAdd(&clk[1], __builtin_amdgcn_s_memrealtime() - r0);
@@ -540,21 +601,34 @@ __device__ __forceinline__ typename C::Acc block_sum(typename C::Acc v, typename
 // HEAVY_BLOCK threads x one partial each must fit the LDS budget of a workgroup
 template <class C>
 constexpr int heavy_block() { return sizeof(typename C::Aff) == 64 ? 256 : 128; }
+// One launch for every split bucket of the batch: buckets with only a few extra segments are summed by one thread
+// each (phase 1), buckets with >= HEAVY_MIN by a workgroup with an LDS tree (phase 2).  Both phases stride over the
+// same list and touch disjoint buckets.  (Rounds 1-3: two launches, msm_heavy + msm_heavy_small.)
 template <class C>
-__global__ void __launch_bounds__(heavy_block<C>()) msm_heavy(const uint32_t* __restrict__ heavy,
-                                                         const uint32_t* __restrict__ info,
-                                                         const uint32_t* __restrict__ offset,
-                                                         const uint32_t* __restrict__ xoff, MsmParams P,
-                                                         typename Ec29<C>::Acc* __restrict__ partial) {
+__global__ void __launch_bounds__(heavy_block<C>(), tail_waves<C>()) msm_heavy(const MsmBatch<C> B, MsmParams P) {
+  tail_prio();
   using E = Ec29<C>;
   constexpr int HEAVY_BLOCK = heavy_block<C>();
   extern __shared__ __align__(16) unsigned char smem[];
   typename E::Acc* sh = reinterpret_cast<typename E::Acc*>(smem);
-  const uint32_t nheavy = info[2];
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const uint32_t* __restrict__ heavy = J.heavy;
+  const uint32_t* __restrict__ offset = J.offset;
+  const uint32_t* __restrict__ xoff = J.xoff;
+  typename E::Acc* __restrict__ partial = J.partial;
+  const uint32_t nheavy = J.info[2];
+  for (uint32_t h = blockIdx.x * HEAVY_BLOCK + threadIdx.x; h < nheavy; h += gridDim.x * HEAVY_BLOCK) {
+    const uint32_t b = heavy[h];
+    const uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
+    if (e >= HEAVY_MIN) continue;
+    typename E::Acc acc = partial[b];
+    for (uint32_t k = 0; k < e; ++k) E::add(acc, partial[P.nbuckets + x0 + k]);
+    partial[b] = acc;
+  }
   for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
     uint32_t b = heavy[h];
     uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
-    if (e < HEAVY_MIN) continue;   // left to msm_heavy_small (uniform per workgroup: no barrier is skipped unevenly)
+    if (e < HEAVY_MIN) continue;   // phase 1's (uniform per workgroup: no barrier is skipped unevenly)
     typename E::Acc acc = E::acc_inf();
     // segment 0 lives at partial[b]; segments 1..e at partial[nbuckets + x0 + s - 1]
     for (uint32_t s = threadIdx.x; s <= e; s += HEAVY_BLOCK) {
@@ -566,45 +640,30 @@ __global__ void __launch_bounds__(heavy_block<C>()) msm_heavy(const uint32_t* __
   }
 }
 
-// split buckets with only a few extra segments: one thread per bucket adds them into partial[b]
-template <class C>
-__global__ void __launch_bounds__(MSM_BLOCK) msm_heavy_small(const uint32_t* __restrict__ heavy,
-                                                             const uint32_t* __restrict__ info,
-                                                             const uint32_t* __restrict__ offset,
-                                                             const uint32_t* __restrict__ xoff, MsmParams P,
-                                                             typename Ec29<C>::Acc* __restrict__ partial) {
-  using E = Ec29<C>;
-  const uint32_t nheavy = info[2];
-  for (uint32_t h = blockIdx.x * MSM_BLOCK + threadIdx.x; h < nheavy; h += gridDim.x * MSM_BLOCK) {
-    const uint32_t b = heavy[h];
-    const uint32_t e = extra_segs(offset[b + 1] - offset[b], P.seg), x0 = xoff[b];
-    if (e >= HEAVY_MIN) continue;
-    typename E::Acc acc = partial[b];
-    for (uint32_t k = 0; k < e; ++k) E::add(acc, partial[P.nbuckets + x0 + k]);
-    partial[b] = acc;
-  }
-}
-
 // ---- K6: bucket reduction  S_w = sum_{k=1}^{K} k * B_{w,k},  K = 2^(c-1) -----------------------------
 // stage 1: thread per chunk of RC consecutive buckets: R_j = sum B_k, A_j = sum (k - j*RC) B_k
 constexpr int RED_CHUNK = 16;
+// A job that continues another MSM's bucket sums (MsmJob::init): a bucket without entries of its own still
+// holds the other MSM's sum, so every bucket is added (infinity is skipped inside the addition).
 template <class C>
-__global__ void __launch_bounds__(MSM_BLOCK) msm_reduce1(const typename Ec29<C>::Acc* __restrict__ partial,
-                                                         const uint32_t* __restrict__ offset, uint32_t nbuckets,
-                                                         typename C::Acc* __restrict__ chunkR,
-                                                         typename C::Acc* __restrict__ chunkA) {
+__global__ void __launch_bounds__(MSM_BLOCK, tail_waves<C>()) msm_reduce1(const MsmBatch<C> B, uint32_t nbuckets) {
+  tail_prio();
   using E = Ec29<C>;   // running sums in the reduced-radix field; the chunk sums leave in the standard layout
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const typename E::Acc* __restrict__ partial = J.partial;
+  const uint32_t* __restrict__ offset = J.offset;
+  const bool always = J.init != nullptr;
   uint32_t j = blockIdx.x * MSM_BLOCK + threadIdx.x;
   uint32_t b0 = j * RED_CHUNK;
   if (b0 >= nbuckets) return;
   typename E::Acc run = E::acc_inf(), acc = E::acc_inf();
   for (int k = RED_CHUNK - 1; k >= 0; --k) {
     uint32_t b = b0 + k;
-    if (b < nbuckets && offset[b + 1] != offset[b]) E::add(run, partial[b]);
+    if (b < nbuckets && (always || offset[b + 1] != offset[b])) E::add(run, partial[b]);
     E::add(acc, run);
   }
-  chunkR[j] = E::to_std(run);
-  chunkA[j] = E::to_std(acc);
+  J.chunkR[j] = E::to_std(run);
+  J.chunkA[j] = E::to_std(acc);
 }
 // stage 2: one workgroup per reduction set (a window, or a slice of the merged bucket set) over its M chunks
 // (chunk m holds buckets m*RC+1 .. (m+1)*RC of the set):
@@ -615,16 +674,16 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_reduce1(const typename Ec29<C>:
 // few doublings, and ONE LDS tree adds the v_t.  The whole kernel is a latency chain of ~40 group operations,
 // so the block is as wide as the register budget allows (BLOCK = 512 for G1, 256 for G2).
 template <class C, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) msm_reduce2(const typename C::Acc* __restrict__ chunkR,
-                                                     const typename C::Acc* __restrict__ chunkA,
-                                                     uint32_t chunks_per_window,
-                                                     typename C::Acc* __restrict__ window_sum,
-                                                     typename C::Acc* __restrict__ window_tot) {
+__global__ void __launch_bounds__(BLOCK, tail_waves<C>()) msm_reduce2(const MsmBatch<C> B, uint32_t chunks_per_window) {
+  tail_prio();
   extern __shared__ __align__(16) unsigned char smem[];
   typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  typename C::Acc* __restrict__ window_sum = J.wsum;        // [0, 64]: set sums
+  typename C::Acc* __restrict__ window_tot = J.wsum + 65;   // [65, 129]: sum of every bucket of the set
   const uint32_t w = blockIdx.x, M = chunks_per_window;
-  const typename C::Acc* R = chunkR + (size_t)w * M;
-  const typename C::Acc* A = chunkA + (size_t)w * M;
+  const typename C::Acc* R = J.chunkR + (size_t)w * M;
+  const typename C::Acc* A = J.chunkA + (size_t)w * M;
   const uint32_t per = (M + BLOCK - 1) / BLOCK;
   const uint32_t lo = threadIdx.x * per, hi = (lo + per < M) ? lo + per : M;
   typename C::Acc sumA = C::acc_inf(), run = C::acc_inf(), wsum = C::acc_inf();
@@ -705,9 +764,12 @@ __device__ __forceinline__ typename C::Acc dbl_coop(const typename C::Acc& p) {
 // c == 0: the window sums already carry their 2^(c w) factor (precomputed tables) -> plain sum.
 // One wave; every lane carries the same running point, the doublings are wave-cooperative (dbl_coop).
 template <class C>
-__global__ void __launch_bounds__(64) msm_fold(const typename C::Acc* __restrict__ window_sum, uint32_t nwin, uint32_t c,
-                                               typename C::Aff* __restrict__ out_aff,
-                                               typename C::Acc* __restrict__ out_acc) {
+__global__ void __launch_bounds__(64) msm_fold(const MsmBatch<C> B, uint32_t nwin, uint32_t c) {
+  tail_prio();
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const typename C::Acc* __restrict__ window_sum = J.wsum;
+  typename C::Aff* __restrict__ out_aff = J.out_aff;
+  typename C::Acc* __restrict__ out_acc = J.out_acc;
   typename C::Acc r = C::acc_inf();
   for (int w = (int)nwin - 1; w >= 0; --w) {
     if (!C::is_inf(r))   // uniform: r is the same on every lane
@@ -745,11 +807,14 @@ __device__ __forceinline__ typename C::Acc wave_allreduce(typename C::Acc v) {
   return wave_get_acc<C>(v, 0);
 }
 template <class C>
-__global__ void __launch_bounds__(128) msm_fold_merged(const typename C::Acc* __restrict__ set_sum,
-                                                       const typename C::Acc* __restrict__ set_tot, uint32_t nsets,
-                                                       uint32_t log2ks, typename C::Aff* __restrict__ out_aff,
-                                                       typename C::Acc* __restrict__ out_acc) {
+__global__ void __launch_bounds__(128, tail_waves<C>()) msm_fold_merged(const MsmBatch<C> B, uint32_t nsets, uint32_t log2ks) {
+  tail_prio();
   __shared__ typename C::Acc ysum;
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const typename C::Acc* __restrict__ set_sum = J.wsum;
+  const typename C::Acc* __restrict__ set_tot = J.wsum + 65;
+  typename C::Aff* __restrict__ out_aff = J.out_aff;
+  typename C::Acc* __restrict__ out_acc = J.out_acc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave == 1) {
     typename C::Acc y = (uint32_t)lane < nsets ? set_sum[lane] : C::acc_inf();

@@ -1,9 +1,8 @@
 // G2 split-bucket combine and first bucket-reduction stage
 #include "msm_stage.cuh"
-int32_t g16_st_heavy_g2(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, void* partial) {
-  return stage_heavy<G2>(ctx, st, S, partial);
+int32_t g16_st_heavy_g2(g16_ctx* ctx, hipStream_t st, const MsmParams& P, const void* batch, uint32_t ny) {
+  return stage_heavy<G2>(ctx, st, P, batch, ny);
 }
-int32_t g16_st_reduce1_g2(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, const void* partial, void* chunkR,
-                          void* chunkA) {
-  return stage_reduce1<G2>(ctx, st, S, partial, chunkR, chunkA);
+int32_t g16_st_reduce1_g2(g16_ctx* ctx, hipStream_t st, const MsmParams& P, const void* batch, uint32_t ny) {
+  return stage_reduce1<G2>(ctx, st, P, batch, ny);
 }

@@ -9,13 +9,20 @@ int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, ui
   return msm_sort_device(ctx, stream, d_scalars, flags, n, table_c, sort, d_live);
 }
 
-// phase 2: accumulate + reduce one point set against a bucket arrangement; d_out_aff / d_out_acc: device
-// pointers (either may be null).  acc_bytes = sizeof(XYZZ accumulator) of the group (128 for G1, 256 for G2).
-static int32_t msm_reduce(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc, const g16_ctx::MsmSort& S, int group,
-                          const void* d_points, void* d_out_aff, void* d_out_acc) {
-  const MsmParams& P = S.P;
-  const size_t asz = group == 1 ? 128 : 256;    // standard XYZZ (chunk sums and later)
-  const size_t psz29 = group == 1 ? 144 : 288;  // reduced-radix XYZZ (bucket partials: accumulate -> heavy -> reduce1)
+// phase 2: accumulate + reduce point sets against their bucket arrangements, `n_accum` jobs per launch (see
+// g16_internal.hpp).  Workspace of a job: bucket sums (reduced radix) | chunkR | chunkA | wsum.
+template <class C>
+static int32_t msm_batch(g16_ctx* ctx, hipStream_t st, const g16_msm_run* runs, int n_accum, int n_tail,
+                         hipEvent_t after_heavy) {
+  if (n_accum < 1 || n_accum > MSM_BATCH_MAX || n_tail < 0 || n_tail > n_accum) {
+    ctx->err = "bad MSM batch";
+    return G16_EINVAL;
+  }
+  const MsmParams& P = runs[0].sort->P;
+  constexpr bool g2 = sizeof(typename C::Aff) == 128;
+  constexpr size_t asz = sizeof(typename C::Acc);             // standard XYZZ (chunk sums and later): 128 / 256 B
+  constexpr size_t psz29 = sizeof(typename Ec29<C>::Acc);     // reduced-radix XYZZ (bucket sums): 144 / 288 B
+  static_assert(asz == (g2 ? 256 : 128) && psz29 == (g2 ? 288 : 144), "accumulator sizes");
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t r = o;
@@ -25,28 +32,60 @@ static int32_t msm_reduce(g16_ctx* ctx, hipStream_t st, g16_ctx::Buf& acc, const
   const size_t nchunks = P.nbuckets / RED_CHUNK;
   const size_t o_partial = take(((size_t)P.nbuckets + P.max_extra) * psz29), o_chunkR = take(nchunks * asz),
                o_chunkA = take(nchunks * asz), o_wsum = take((size_t)(2 * 64 + 2) * asz);
-  int32_t rc = ensure(ctx, acc, o);
-  if (rc) return rc;
-  char* ws = (char*)acc.p;
-  void *partial = ws + o_partial, *chunkR = ws + o_chunkR, *chunkA = ws + o_chunkA, *wsum = ws + o_wsum;
-  if (group == 1) {
-    if ((rc = g16_st_accum_g1(ctx, st, S, d_points, partial))) return rc;
-    if ((rc = g16_st_heavy_g1(ctx, st, S, partial))) return rc;
-    if ((rc = g16_st_reduce1_g1(ctx, st, S, partial, chunkR, chunkA))) return rc;
-    return g16_st_reduce2_g1(ctx, st, S, chunkR, chunkA, wsum, d_out_aff, d_out_acc);
+  MsmBatch<C> B;
+  memset(&B, 0, sizeof B);
+  for (int j = 0; j < n_accum; ++j) {
+    const g16_ctx::MsmSort& S = *runs[j].sort;
+    const MsmParams& Q = S.P;
+    if (Q.n != P.n || Q.c != P.c || Q.nwin != P.nwin || Q.nbuckets != P.nbuckets || Q.seg != P.seg ||
+        Q.tables != P.tables || Q.max_extra != P.max_extra) {
+      ctx->err = "MSM batch: the jobs do not share their launch parameters";
+      return G16_EINVAL;
+    }
+    int32_t rc = ensure(ctx, *runs[j].acc, o);
+    if (rc) return rc;
+    char* ws = (char*)runs[j].acc->p;
+    MsmJob<C>& J = B.job[j];
+    J.points = (const typename Ec29<C>::Tab*)runs[j].d_points;
+    J.entries = S.entries;
+    J.offset = S.offset;
+    J.xseg = S.xseg;
+    J.info = S.info;
+    J.perm = S.perm;
+    J.heavy = S.heavy;
+    J.xoff = S.xoff;
+    J.partial = (typename Ec29<C>::Acc*)(ws + o_partial);
+    J.init = (const typename Ec29<C>::Acc*)runs[j].init_partial;
+    J.chunkR = (typename C::Acc*)(ws + o_chunkR);
+    J.chunkA = (typename C::Acc*)(ws + o_chunkA);
+    J.wsum = (typename C::Acc*)(ws + o_wsum);
+    J.out_aff = (typename C::Aff*)runs[j].d_out_aff;
+    J.out_acc = (typename C::Acc*)runs[j].d_out_acc;
   }
-  if ((rc = g16_st_accum_g2(ctx, st, S, d_points, partial))) return rc;
-  if ((rc = g16_st_heavy_g2(ctx, st, S, partial))) return rc;
-  if ((rc = g16_st_reduce1_g2(ctx, st, S, partial, chunkR, chunkA))) return rc;
-  return g16_st_reduce2_g2(ctx, st, S, chunkR, chunkA, wsum, d_out_aff, d_out_acc);
+  // (the bucket sums come first in the workspace: g16_msm_partial_ptr)
+  int32_t rc;
+  if ((rc = g2 ? g16_st_accum_g2(ctx, st, P, &B, n_accum) : g16_st_accum_g1(ctx, st, P, &B, n_accum))) return rc;
+  if ((rc = g2 ? g16_st_heavy_g2(ctx, st, P, &B, n_accum) : g16_st_heavy_g1(ctx, st, P, &B, n_accum))) return rc;
+  if (after_heavy) HIPCHK(ctx, hipEventRecord(after_heavy, st));
+  if (!n_tail) return G16_OK;
+  if ((rc = g2 ? g16_st_reduce1_g2(ctx, st, P, &B, n_tail) : g16_st_reduce1_g1(ctx, st, P, &B, n_tail))) return rc;
+  const bool narrow = runs[0].sort->narrow_tail;
+  return g2 ? g16_st_reduce2_g2(ctx, st, P, narrow, &B, n_tail) : g16_st_reduce2_g1(ctx, st, P, narrow, &B, n_tail);
+}
+int32_t g16_msm_batch(g16_ctx* ctx, hipStream_t stream, int group, const g16_msm_run* runs, int n_accum, int n_tail,
+                      hipEvent_t after_heavy) {
+  return group == 1 ? msm_batch<G1>(ctx, stream, runs, n_accum, n_tail, after_heavy)
+                    : msm_batch<G2>(ctx, stream, runs, n_accum, n_tail, after_heavy);
 }
 int32_t g16_msm_reduce_g1(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
                           const void* d_points, void* d_out_aff, void* d_out_acc) {
-  return msm_reduce(ctx, stream, acc, sort, 1, d_points, d_out_aff, d_out_acc);
+  const g16_msm_run run{&sort, &acc, d_points, d_out_aff, d_out_acc, nullptr};
+  return msm_batch<G1>(ctx, stream, &run, 1, 1, nullptr);
 }
 int32_t g16_msm_reduce_g2(g16_ctx* ctx, hipStream_t stream, g16_ctx::Buf& acc, const g16_ctx::MsmSort& sort,
                           const void* d_points, void* d_out_aff, void* d_out_acc) {
-  return msm_reduce(ctx, stream, acc, sort, 2, d_points, d_out_aff, d_out_acc);
+  const g16_msm_run run{&sort, &acc, d_points, d_out_aff, d_out_acc, nullptr};
+  return msm_batch<G2>(ctx, stream, &run, 1, 1, nullptr);
 }
 // one complete MSM on the context's main stream
 static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
@@ -62,7 +101,8 @@ static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32
     if (rc) return rc;
     d_points = ctx->stage_p29.p;
   }
-  return msm_reduce(ctx, ctx->stream, ctx->lane[0].acc, ctx->sort[0], group, d_points, d_out_aff, d_out_acc);
+  return group == 1 ? g16_msm_reduce_g1(ctx, ctx->stream, ctx->lane[0].acc, ctx->sort[0], d_points, d_out_aff, d_out_acc)
+                    : g16_msm_reduce_g2(ctx, ctx->stream, ctx->lane[0].acc, ctx->sort[0], d_points, d_out_aff, d_out_acc);
 }
 int32_t g16_msm_device_g1(g16_ctx* ctx, const void* s, uint32_t f, const void* p, size_t n, void* aff, void* acc,
                           uint32_t table_c, const uint32_t* d_live) {

@@ -7,58 +7,50 @@
 
 using namespace g16;
 
+// `batch`: MsmBatch<C> with `ny` jobs that share the launch parameters P (same n, same window: the G1 MSMs of a proof)
 template <class C>
-static int32_t stage_accum(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, const void* points, void* partial) {
-  const MsmParams& P = S.P;
+static int32_t stage_accum(g16_ctx* ctx, hipStream_t st, const MsmParams& P, const void* batch, uint32_t ny) {
   const bool g2 = sizeof(typename C::Aff) == 128;
   const uint32_t ntask = P.nbuckets + P.max_extra;
-  KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, (ntask + ACC_BLOCK - 1) / ACC_BLOCK,
-             ACC_BLOCK, 0, (const typename Ec29<C>::Tab*)points, S.entries, S.offset, S.xseg, S.info, S.perm, P,
-             (typename Ec29<C>::Acc*)partial, ctx->profiling ? ctx->clk_buf : (unsigned long long*)nullptr);
+  KLAUNCH_ON(ctx, st, g2 ? "msm_accum_g2" : "msm_accum_g1", msm_accum<C>, dim3((ntask + ACC_BLOCK - 1) / ACC_BLOCK, ny),
+             ACC_BLOCK, 0, *(const MsmBatch<C>*)batch, P, ctx->profiling ? ctx->clk_buf : (unsigned long long*)nullptr);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
 
 template <class C>
-static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, void* partial_) {
-  const MsmParams& P = S.P;
+static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const MsmParams& P, const void* batch, uint32_t ny) {
   const bool g2 = sizeof(typename C::Aff) == 128;
-  auto* partial = (typename Ec29<C>::Acc*)partial_;
-  // Grid sizes: both kernels loop grid-stride over the list of split buckets (all but empty for uniform or circom-like
-  // scalars).  In the timeline of a proof these launches look expensive (3-4 ms, against 0.05 ms alone) because their
-  // workgroups queue behind the accumulate waves of the other lanes; shrinking the grids to 128 / 32 workgroups was
-  // measured (tools/ab_builds.sh, profiles/r02_ab_heavy_grid.txt): no change in proofs/s or latency -- the in-order
-  // reduce behind them waits for the same slots -- and 30 % slower MSMs for scalars with thousands of split buckets
-  // (tools/perf_skew.py "256 values": 3.92 -> 5.11 ms).  Kept at 1024 / 256.
-  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, 1024, heavy_block<C>(),
-             heavy_block<C>() * sizeof(typename Ec29<C>::Acc), S.heavy, S.info, S.offset, S.xoff, P, partial);
-  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy_small<C>, 256, MSM_BLOCK, 0, S.heavy, S.info,
-             S.offset, S.xoff, P, partial);
+  // Grid size: the kernel loops grid-stride over the list of split buckets (all but empty for uniform or circom-like
+  // scalars).  In the timeline of a proof this launch looks expensive (milliseconds, against 0.05 ms alone) because
+  // its workgroups queue behind the accumulate waves of the other streams; shrinking the grid to 128 workgroups was
+  // measured in round 2 (profiles/r02_ab_heavy_grid.txt): no change in proofs/s or latency -- the in-order reduce
+  // behind it waits for the same slots -- and 30 % slower MSMs for scalars with thousands of split buckets
+  // (tools/perf_skew.py "256 values": 3.92 -> 5.11 ms).
+  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, dim3(ny > 1 ? 512 : 1024, ny), heavy_block<C>(),
+             heavy_block<C>() * sizeof(typename Ec29<C>::Acc), *(const MsmBatch<C>*)batch, P);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
 
 template <class C>
-static int32_t stage_reduce1(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, const void* partial,
-                             void* chunkR, void* chunkA) {
-  const MsmParams& P = S.P;
+static int32_t stage_reduce1(g16_ctx* ctx, hipStream_t st, const MsmParams& P, const void* batch, uint32_t ny) {
   const bool g2 = sizeof(typename C::Aff) == 128;
   const size_t nchunks = P.nbuckets / RED_CHUNK;
   KLAUNCH_ON(ctx, st, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>,
-             (uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0, (const typename Ec29<C>::Acc*)partial, S.offset,
-             P.nbuckets, (typename C::Acc*)chunkR, (typename C::Acc*)chunkA);
+             dim3((uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), ny), MSM_BLOCK, 0, *(const MsmBatch<C>*)batch,
+             P.nbuckets);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
 
-// wsum: room for 2 * 64 + 2 accumulators
+// MsmJob::wsum: room for 2 * 64 + 2 accumulators
 template <class C>
-static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::MsmSort& S, const void* chunkR,
-                                  const void* chunkA, void* wsum_, void* d_out_aff, void* d_out_acc) {
-  const MsmParams& P = S.P;
+static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams& P, bool narrow_tail, const void* batch,
+                                  uint32_t ny) {
   const bool g2 = sizeof(typename C::Aff) == 128;
   const size_t nchunks = P.nbuckets / RED_CHUNK;
-  auto* wsum = (typename C::Acc*)wsum_;
+  const MsmBatch<C>& B = *(const MsmBatch<C>*)batch;
   // reduction sets: the windows themselves, or <= 64 slices of the merged bucket set.  reduce2 is a latency chain
   // whose length grows with the chunks per thread, so the slices are as small as the 64 lanes of msm_fold_merged
   // allow: 512 chunks (2^13 buckets) per slice at c = 20 -> 64 workgroups, one chunk per thread (G1) / two (G2).
@@ -71,7 +63,6 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::M
     nsets = (uint32_t)(nchunks / cps);
     for (uint32_t ks = cps * RED_CHUNK; ks > 1; ks >>= 1) ++log2ks;
   }
-  auto* wtot = wsum + 65;
   // Workgroup width of reduce2.  The kernel is a latency chain (serial chunk sums -> Hillis-Steele suffix scan ->
   // tree), and every scan step costs one group addition on EVERY wave of the workgroup.  Wide workgroups (512 / 256
   // threads: one chunk per thread) have the shortest chain; narrow ones (128 / 64 threads: four chunks per thread,
@@ -82,26 +73,22 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const g16_ctx::M
   // 5.7 ms narrow.  G16_R2_WIDTH = 0 / 1 / 2 forces wide / narrow / a single wave per slice everywhere.
   constexpr int R2B = sizeof(typename C::Aff) == 64 ? 512 : 256;
   constexpr int R2N = R2B / 4;
-  const auto* cR = (const typename C::Acc*)chunkR;
-  const auto* cA = (const typename C::Acc*)chunkA;
   const uint32_t cps = (uint32_t)(nchunks / nsets);
   const char* nm = g2 ? "msm_reduce2_g2" : "msm_reduce2_g1";
-  switch (g16_env().r2_width >= 0 ? g16_env().r2_width : (S.narrow_tail ? 1 : 0)) {
+  switch (g16_env().r2_width >= 0 ? g16_env().r2_width : (narrow_tail ? 1 : 0)) {
     case 0:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), nsets, R2B, R2B * sizeof(typename C::Acc), cR, cA, cps, wsum, wtot);
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), dim3(nsets, ny), R2B, R2B * sizeof(typename C::Acc), B, cps);
       break;
     case 2:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, 64>), nsets, 64, 64 * sizeof(typename C::Acc), cR, cA, cps, wsum, wtot);
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, 64>), dim3(nsets, ny), 64, 64 * sizeof(typename C::Acc), B, cps);
       break;
     default:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), nsets, R2N, R2N * sizeof(typename C::Acc), cR, cA, cps, wsum, wtot);
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), dim3(nsets, ny), R2N, R2N * sizeof(typename C::Acc), B, cps);
   }
   if (P.tables)
-    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, 1, 128, 0, wsum, wtot, nsets, log2ks,
-               (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, dim3(1, ny), 128, 0, B, nsets, log2ks);
   else
-    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, 1, 64, 0, wsum, nsets, P.c,
-               (typename C::Aff*)d_out_aff, (typename C::Acc*)d_out_acc);
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, dim3(1, ny), 64, 0, B, nsets, P.c);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }

@@ -369,61 +369,93 @@ static int32_t upload_witness(g16_ctx* ctx, const g16_pkey* k, const void* witne
   return G16_OK;
 }
 
+// C1 and H1 enter the proof only as their sum (pi_c = ... + H + C, prover.nim:301-302), and both point sets are
+// registered with the same window, i.e. over the same bucket set: the H accumulation then STARTS from C1's bucket sums
+// instead of from infinity, and the pair needs one bucket reduction (reduce1 / reduce2 / fold) instead of two.  The
+// C1 slot of the record stays at infinity.  G16_CHAIN_CH=0 restores two separate MSMs.
+static bool chain_c_into_h(const g16_pkey* k) {
+  return g16_env().chain_ch && k->w_hi > k->w_lo && k->h_hi > k->h_lo && k->C1->c == k->H1->c;
+}
+
 // The four MSMs that consume the witness (A1, B1, B2, C1: prover.nim:282, 288, 294, 302) on the lane streams.  The
-// witness' signed-digit bucket arrangement is computed once (lane 0) and shared; the four accumulate/reduce pipelines
-// run on four streams so that their latency-bound tails overlap with the other pipelines' accumulation.  Nothing is
-// waited for here.  `after` (optional): an event the accumulations wait for in addition to the sort -- the quotient's
-// last kernel (G16_QUOTIENT_FIRST / G16_LANES_AFTER_QUOTIENT experiments): the NTT passes are large workgroups (512
-// threads + 80 KB of LDS) that are starved for milliseconds when the long-running, register-filling accumulate waves
-// of four lanes get to the CUs first; the sort itself is memory-bound and overlaps the quotient.
-static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, uint32_t flags, const ProveBufs& b,
-                                   hipEvent_t after) {
-  const uint32_t wit_mont = (flags & G16_SCALARS_MONT) ? 1u : 0u;
-  int32_t rc;
-  const uint32_t wflags = wit_mont ? G16_SCALARS_MONT : 0u;
+// witness' signed-digit bucket arrangement is computed once (lane 0) and shared; the four accumulate / reduce pipelines
+// run on four streams so that their latency-bound tails overlap the other pipelines' accumulation.  Nothing is waited
+// for here.  Round 4 measured four other schedules against this one, same box, same session (profiles/r04_ab_*.txt):
+//  * A1, B1, C1 as ONE batched launch sequence on one stream (every stage kernel takes blockIdx.y = MSM: three-wide
+//    tails, 15 launches and 2 streams less): 110.2 vs 115.2 proofs/s.  Kept as G16_G1_BATCH=1.
+//  * one accumulate stream per context with the tails on the lanes (a context then offers one accumulate kernel at a
+//    time): 110.7 vs 117.4, and 33 / 10 proofs/s with 4 / 5 proofs in flight (the runtime's cross-stream waits stall).
+//  * one accumulate stream for ALL in-flight proofs of the device: 8-12 proofs/s (stalls of 10-45 ms at the waits).
+//  * an admission gate (the whole front of a proof -- upload, both sorts, buildABC, quotient -- first, then at most n
+//    proofs past the gate, 4-6 in flight): 119.2-120.2 vs 119.5 -- the share of wall time without a resident
+//    accumulate kernel falls from 12 % to 8 % (tools/overlap.py) and the throughput does not move.
+// The step is bound by the instructions of ALL its kernels; what these schedules rearrange is latency.
+// `after` (optional): an event the accumulations wait for in addition to the sort -- the quotient's last kernel
+// (G16_QUOTIENT_FIRST / G16_LANES_AFTER_QUOTIENT experiments).
+// phase 1: the bucket arrangements of the witness (lane 0; lane 1 for the live pairs of B1 / B2)
+static int32_t launch_witness_sorts(g16_ctx* ctx, const g16_pkey* k, uint32_t flags) {
+  const uint32_t wflags = (flags & G16_SCALARS_MONT) ? G16_SCALARS_MONT : 0u;
   const size_t nw = k->w_hi - k->w_lo;
-  if (nw) {
-    g16_ctx::MsmLane* L = ctx->lane;
-    // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES (read once per process, g16_env) reassigns them
-    const int la = g16_env().g1_lanes[0], lb = g16_env().g1_lanes[1], lc = g16_env().g1_lanes[2];
-    const u256* d_wr = b.d_w + k->w_lo;
-    HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
-    for (auto& srt : ctx->sort) srt.narrow_tail = true;   // proofs overlap their MSM tails with other work (msm_stage.cuh)
-    if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
-    for (int i = 1; i < 4; ++i)   // (lane 1 sorts for itself when B is sparse: it needs the witness, not lane 0's sort)
-      HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, i == 1 && k->liveB ? ctx->ev_a : ctx->ev_b, 0));
-    if (after)
-      for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, after, 0));
-    // B1 / B2 with many (0,0) points: their own arrangement of the witness (live pairs only), built on B2's lane
-    // while lane 0 arranges the full witness
-    const g16_ctx::MsmSort* sortB = &ctx->sort[0];
-    if (k->liveB) {
-      if ((rc = g16_msm_sort(ctx, L[1].stream, d_wr, wflags, nw, k->B2->c, ctx->sort[3], k->liveB))) return rc;
-      HIPCHK(ctx, hipEventRecord(ctx->ev_b2, L[1].stream));
-      HIPCHK(ctx, hipStreamWaitEvent(L[lb].stream, ctx->ev_b2, 0));
-      sortB = &ctx->sort[3];
-    }
-    if ((rc = g16_msm_reduce_g2(ctx, L[1].stream, L[1].acc, *sortB, k->B2->d_tables, nullptr, b.slots + PART_B2)))
-      return rc;
-    const g16_ctx::MsmSort* sortA = &ctx->sort[0];
-    if (k->liveA) {   // likewise A1, on its own lane
-      if ((rc = g16_msm_sort(ctx, L[la].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[2], k->liveA))) return rc;
-      sortA = &ctx->sort[2];
-    }
-    if ((rc = g16_msm_reduce_g1(ctx, L[la].stream, L[la].acc, *sortA, k->A1->d_tables, nullptr, b.slots + PART_A)))
-      return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[lb].stream, L[lb].acc, *sortB, k->B1->d_tables, nullptr, b.slots + PART_B1)))
-      return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, L[lc].stream, L[lc].acc, ctx->sort[0], k->C1->d_tables, nullptr, b.slots + PART_C)))
-      return rc;
-    for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipEventRecord(L[i].done, L[i].stream));
+  if (!nw) return G16_OK;
+  int32_t rc;
+  g16_ctx::MsmLane* L = ctx->lane;
+  ProveBufs b;
+  if ((rc = prove_bufs(ctx, k, b))) return rc;
+  const u256* d_wr = b.d_w + k->w_lo;
+  HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
+  for (auto& srt : ctx->sort) srt.narrow_tail = true;   // proofs overlap their MSM tails with other work (msm_stage.cuh)
+  if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
+  if (k->liveA)   // A1 with many (0,0) points: its own arrangement, behind the shared one
+    if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[2], k->liveA))) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
+  // B1 / B2 with many (0,0) points: their own arrangement of the witness (live pairs only), built on B2's lane
+  // while lane 0 arranges the full witness
+  if (k->liveB) {
+    HIPCHK(ctx, hipStreamWaitEvent(L[1].stream, ctx->ev_a, 0));
+    if ((rc = g16_msm_sort(ctx, L[1].stream, d_wr, wflags, nw, k->B2->c, ctx->sort[3], k->liveB))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_b2, L[1].stream));
   }
   return G16_OK;
 }
+// phase 2: accumulate + reduce A1, B1, B2, C1 against them
+static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const ProveBufs& b, hipEvent_t after) {
+  int32_t rc;
+  const size_t nw = k->w_hi - k->w_lo;
+  if (!nw) return G16_OK;
+  g16_ctx::MsmLane* L = ctx->lane;
+  const bool batch = g16_env().g1_batch != 0;
+  const bool chain = chain_c_into_h(k);
+  // lanes of the three G1 MSMs (A1, B1, C1); G16_G1_LANES (read once per process, g16_env) reassigns them
+  const int la = batch ? 0 : g16_env().g1_lanes[0], lb = batch ? 0 : g16_env().g1_lanes[1],
+            lc = batch ? 0 : g16_env().g1_lanes[2];
+  const int nlanes = batch ? 2 : 4;
+  const g16_ctx::MsmSort* sortA = k->liveA ? &ctx->sort[2] : &ctx->sort[0];
+  const g16_ctx::MsmSort* sortB = k->liveB ? &ctx->sort[3] : &ctx->sort[0];
+  // workspaces: the accumulate buffers of lanes 1, 0, 2, 3 serve B2, A1, B1, C1 in every mode
+  const g16_msm_run runB2{sortB, &L[1].acc, k->B2->d_tables, nullptr, b.slots + PART_B2, nullptr};
+  g16_msm_run runs[3] = {{sortA, &L[0].acc, k->A1->d_tables, nullptr, b.slots + PART_A, nullptr},
+                         {sortB, &L[2].acc, k->B1->d_tables, nullptr, b.slots + PART_B1, nullptr},
+                         {&ctx->sort[0], &L[3].acc, k->C1->d_tables, nullptr, b.slots + PART_C, nullptr}};
+  for (int i = 1; i < nlanes; ++i)   // (lane 1 sorted for itself when B is sparse)
+    HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, i == 1 && k->liveB ? ctx->ev_b2 : ctx->ev_b, 0));
+  if (k->liveB) HIPCHK(ctx, hipStreamWaitEvent(L[lb].stream, ctx->ev_b2, 0));
+  if (k->liveA && la != 0) HIPCHK(ctx, hipStreamWaitEvent(L[la].stream, ctx->ev_b, 0));
+  if (after)
+    for (int i = 0; i < nlanes; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, after, 0));
+  if ((rc = g16_msm_batch(ctx, L[1].stream, 2, &runB2, 1, 1, nullptr))) return rc;
+  if (batch) {
+    if ((rc = g16_msm_batch(ctx, L[0].stream, 1, runs, 3, chain ? 2 : 3, chain ? ctx->ev_c : nullptr))) return rc;
+  } else {
+    if ((rc = g16_msm_batch(ctx, L[la].stream, 1, &runs[0], 1, 1, nullptr))) return rc;
+    if ((rc = g16_msm_batch(ctx, L[lb].stream, 1, &runs[1], 1, 1, nullptr))) return rc;
+    if ((rc = g16_msm_batch(ctx, L[lc].stream, 1, &runs[2], 1, chain ? 0 : 1, chain ? ctx->ev_c : nullptr))) return rc;
+  }
+  for (int i = 0; i < nlanes; ++i) HIPCHK(ctx, hipEventRecord(L[i].done, L[i].stream));
+  return G16_OK;
+}
 
-// the H MSM over this key's domain range (prover.nim:301) on the main stream, then join the lanes and hand out the
-// five partials.  d_qs_slice: the H scalars of [h_lo, h_hi), Montgomery.
+// the H MSM over this key's domain range (prover.nim:301), then join the lanes and hand out the five partials.
+// d_qs_slice: the H scalars of [h_lo, h_hi), Montgomery.
 static int32_t launch_h_sort(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice) {
   const size_t nh = k->h_hi - k->h_lo;
   ctx->sort[1].narrow_tail = true;
@@ -434,13 +466,17 @@ static int32_t launch_h_and_collect(g16_ctx* ctx, const g16_pkey* k, const u256*
   int32_t rc;
   hipStream_t M = ctx->stream;
   const size_t nw = k->w_hi - k->w_lo, nh = k->h_hi - k->h_lo;
+  const int nlanes = g16_env().g1_batch ? 2 : 4;
   if (nh) {
     if (!sorted && (rc = launch_h_sort(ctx, k, d_qs_slice))) return rc;
-    if ((rc = g16_msm_reduce_g1(ctx, M, ctx->lane[4].acc, ctx->sort[1], k->H1->d_tables, nullptr, b.slots + PART_H)))
-      return rc;
+    const bool chain = chain_c_into_h(k);
+    const g16_msm_run run{&ctx->sort[1], &ctx->lane[4].acc, k->H1->d_tables, nullptr, b.slots + PART_H,
+                          chain ? g16_msm_partial_ptr(ctx->lane[3].acc) : nullptr};
+    if (chain) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->ev_c, 0));   // C1's bucket sums are final
+    if ((rc = g16_msm_batch(ctx, M, 1, &run, 1, 1, nullptr))) return rc;
   }
   if (nw)
-    for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->lane[i].done, 0));
+    for (int i = 0; i < nlanes; ++i) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->lane[i].done, 0));
   HIPCHK(ctx, hipMemcpyAsync(out_partials, b.slots, PART_BYTES,
                              (flags & G16_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
   // G16_NO_HOST_SYNC (device output only): the record is complete in stream order; the caller's next operation on
@@ -466,7 +502,8 @@ static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* 
   // proofs/s and 13.1 vs 12.0 ms single-proof latency -- the quotient does finish 6 ms earlier, but the H accumulate
   // then competes with four lanes instead of running last and alone, and the proof ends no sooner.  Rejected.
   if (!g16_env().quotient_first) {
-    if ((rc = launch_witness_msms(ctx, k, flags, b, nullptr))) return rc;
+    if ((rc = launch_witness_sorts(ctx, k, flags))) return rc;
+    if ((rc = launch_witness_msms(ctx, k, b, nullptr))) return rc;
     if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc))) return rc;
     if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs))) return rc;
     return launch_h_and_collect(ctx, k, b.d_qs + k->h_lo, flags, b, out_partials);
@@ -481,7 +518,8 @@ static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* 
     HIPCHK(ctx, hipEventRecord(ctx->ev_q, ctx->stream));
     after = ctx->ev_q;
   }
-  if ((rc = launch_witness_msms(ctx, k, flags, b, after))) return rc;
+  if ((rc = launch_witness_sorts(ctx, k, flags))) return rc;
+  if ((rc = launch_witness_msms(ctx, k, b, after))) return rc;
   return launch_h_and_collect(ctx, k, b.d_qs + k->h_lo, flags, b, out_partials, true);
 }
 
@@ -523,7 +561,8 @@ extern "C" int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* k, con
     if (hipEventRecord(ctx->ev_q, ctx->stream) != hipSuccess) rc = G16_EHIP;
     after = ctx->ev_q;
   }
-  if (!rc) rc = launch_witness_msms(ctx, k, flags, b, after);
+  if (!rc) rc = launch_witness_sorts(ctx, k, flags);
+  if (!rc) rc = launch_witness_msms(ctx, k, b, after);
   if (!rc && !(flags & G16_NO_HOST_SYNC) && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // the task outputs are complete; the lanes run on
     ctx->err = "hipStreamSynchronize failed";
     rc = G16_EHIP;

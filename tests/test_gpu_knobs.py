@@ -70,6 +70,10 @@ KNOBS = [
     {"G16_INF_COMPACT": "101", "G16_MSM_SEG": "8"},            # compaction off; short segments: many split buckets
     {"G16_NTT_TILE": "1024", "G16_QUOTIENT_FIRST": "1", "G16_LANES_AFTER_QUOTIENT": "1"},
     {"G16_NTT_TILE": "4096", "G16_G1_LANES": "302", "G16_STREAM_PRIO": "nnnnnn"},
+    {"G16_G1_BATCH": "1"},                                      # A1, B1, C1 as one batched launch sequence (round 4)
+    {"G16_G1_BATCH": "1", "G16_CHAIN_CH": "0", "G16_INF_COMPACT": "0", "G16_MSM_SEG": "8"},   # ... with own sorts, split buckets
+    {"G16_CHAIN_CH": "0"},                                      # C1 and H1 as two separate MSMs (rounds 1-3)
+    {"G16_CHAIN_CH": "1", "G16_MSM_SEG": "8", "G16_INF_COMPACT": "0"},   # the chain across split buckets and own sorts
 ]
 
 

@@ -20,6 +20,7 @@
 int main(int argc, char** argv) {
   const char *lpath = nullptr, *zpath = nullptr, *wpath = nullptr;
   int steps = 96, inflight = 3, reps = 3;
+  if (const char* v = getenv("AB_INFLIGHT")) inflight = atoi(v);   // (tools/ab_rounds.sh: per-entry "@AB_INFLIGHT=4")
   bool key_per_ctx = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];

@@ -96,7 +96,8 @@ def hot_loop_mix(disasm, kernel_regex, whole_kernel=False):
             if off >= 32768:
                 off -= 65536
             tgt = addr + 4 + 4 * off
-            if tgt < addr and addr - tgt > best[0]:
+            # (a backward branch to the kernel's exit block is not a loop: its range would hold the s_endpgm)
+            if tgt < addr and addr - tgt > best[0] and not any(o == "s_endpgm" and tgt <= a <= addr for a, o, _ in ins):
                 best = (addr - tgt, tgt, addr)
     _, lo, hi = best
     counts = collections.Counter(op for addr, op, _ in ins if lo <= addr <= hi)
