@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 # worse).  Read by the HIP runtime when it initialises, so it is set before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+GATHER_CEILING_GB_S = 2200.0     # measured ceiling of random table gathers (profiles/r03_ubench_affine_g2.txt)
 NWITNESS = 3          # distinct satisfying witnesses the timed steps rotate over (w_0 = 3, 5, 7; same k_i, same key)
 
 
@@ -50,6 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=288,
                     help="timed proofs (default 288: a ~2.5-s timed region at 2^20; round 2's 96 steps = 0.9 s were within box noise)")
     ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps proofs, barriers on both sides) is run this many times; "
+                         "`value` / `ms_per_step` are the median run, every run is listed in `value_runs` (a 20-step "
+                         "region is 0.17 s: one such run is the noisiest number this file can print)")
     ap.add_argument("--log2n", type=int, default=20, help="domain size 2^log2n (constraints m = 2^log2n - 2)")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,9 +111,9 @@ def build_inputs(args, ctx, rank, world, dist):
     from nim_groth16_amd.synthetic import SplitMix64, squaringChain
     n = 1 << args.log2n
     m = n - 2
+    import shutil
     import tempfile
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    path = os.path.join(shm, f"g16bench_{os.environ.get('MASTER_PORT', '0')}_{args.log2n}.pkl")
+    path = None
     if rank == 0:
         r1cs, wit0 = squaringChain(m, seed=4)
         # more satisfying witnesses of the SAME circuit: the chain constants k_i (which are what the key depends on)
@@ -118,17 +123,21 @@ def build_inputs(args, ctx, rank, world, dist):
         tox = ToxicWaste(*[rng.fr() for _ in range(5)])
         zkey = fakeCircuitSetup(r1cs, tox, 1, ctx)           # scalar side on the host, every `y ** gen` on the GPU
         if world > 1:
-            with open(path + ".tmp", "wb") as f:
+            # a directory only this user can enter (mkdtemp: mode 0700, unpredictable name), its path handed to the
+            # other ranks through the process group -- not a fixed name in world-writable /dev/shm
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            path = os.path.join(tempfile.mkdtemp(prefix="g16bench_", dir=shm), "key.pkl")
+            with open(path, "wb") as f:
                 pickle.dump((zkey, wits), f, protocol=pickle.HIGHEST_PROTOCOL)
-            os.replace(path + ".tmp", path)
     if world > 1:
-        dist.barrier()
+        box = [path]
+        dist.broadcast_object_list(box, src=0)
         if rank != 0:
-            with open(path, "rb") as f:
+            with open(box[0], "rb") as f:
                 zkey, wits = pickle.load(f)
         dist.barrier()
         if rank == 0:
-            os.remove(path)
+            shutil.rmtree(os.path.dirname(path), ignore_errors=True)
     return zkey, wits
 
 
@@ -304,13 +313,16 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     # next to the uncontended one below.  (Events around all ~110 launches of a proof would cost ~3 % of throughput.)
     ctx.profile(2 if rank == 0 else 0)
     ctx.profile_reset()
-    t0 = time.perf_counter()
-    run(args.steps, hbm=args.witness == "hbm")
-    barrier()
-    dt = time.perf_counter() - t0
+    runs = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps, hbm=args.witness == "hbm")
+        barrier()
+        runs.append(allmax(time.perf_counter() - t0))
     rep = ctx.profile_report() if rank == 0 else {}
     ctx.profile(False)
-    dt = allmax(dt)
+    dt = sorted(runs)[len(runs) // 2]          # the median run
     proofs_done = args.steps * (1 if shard or world == 1 else world)
     value = proofs_done / dt
     # the other witness placement, same protocol (barrier, K' steps, barrier, max over ranks), reported as an extra key
@@ -332,7 +344,7 @@ def measure(args, rank, world, local, dist, coll_dev, state):
         sp.close()
 
     state.update(zkey=zkey, wits=wits, mask=mask, proofs=proofs, ctx=ctx, value=value, dt=dt, value_other=value_other,
-                 lat_ms=lat_ms, inflight=inflight, shard=shard)
+                 lat_ms=lat_ms, inflight=inflight, shard=shard, value_runs=[round(proofs_done / t, 4) for t in runs])
     if rank != 0:
         return
     # ---- roofline of the dominant kernel (rank 0; nothing else runs on this GPU from here on) -------------------------
@@ -345,22 +357,28 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     # The same kernel with the GPU to itself: `reps` stand-alone registered MSMs over the same point array and the
     # same witness, every launch bracketed by HIP events on its stream and stamping the shader clock from inside.
     reps = 5
+
+    def isolated(group):
+        pts = zkey.pPoints.pointsB2 if group == 2 else zkey.pPoints.pointsA1
+        h = ctx.register_points(group, pts, zkey.header.nvars)
+        cW = h.info()
+        ctx.msm_points(h, d_w[0].data_ptr(), mont=False, device=True)
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.profile_clock()                              # reset the in-kernel clock sums
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctx.msm_points(h, d_w[0].data_ptr(), mont=False, device=True)
+        wall = (time.perf_counter() - t1) / reps * 1e3
+        ghz = ctx.profile_clock()                        # s_memtime / s_memrealtime inside those launches
+        r = ctx.profile_report()
+        ctx.profile(False)
+        h.release()
+        return r, wall, ghz, cW
+
     grp = 2 if dom.endswith("g2") else 1
-    pts = zkey.pPoints.pointsB2 if grp == 2 else zkey.pPoints.pointsA1
-    hA = ctx.register_points(grp, pts, zkey.header.nvars)
-    c, W = hA.info()
-    ctx.msm_points(hA, d_w[0].data_ptr(), mont=False, device=True)
-    ctx.profile(True)
-    ctx.profile_reset()
-    ctx.profile_clock()                              # reset the in-kernel clock sums
-    t1 = time.perf_counter()
-    for _ in range(reps):
-        ctx.msm_points(hA, d_w[0].data_ptr(), mont=False, device=True)
-    msm_wall = (time.perf_counter() - t1) / reps * 1e3
-    clock_ghz = ctx.profile_clock()                  # s_memtime / s_memrealtime inside those launches
-    rep1 = ctx.profile_report()
-    ctx.profile(False)
-    hA.release()
+    rep1, msm_wall, clock_ghz, (c, W) = isolated(grp)
+    rep_other = isolated(3 - grp)[0] if not shard else None
     iso = rep1[dom]["total_ms"] / rep1[dom]["calls"]
     achieved = alg / (iso * 1e-3) / 1e9
     static = static_inputs(args, shard, dom)
@@ -374,9 +392,32 @@ def measure(args, rank, world, local, dist, coll_dev, state):
                      "the same points and witness right after the timed region); contended_...: the same events inside "
                      "the timed region, where ~15 streams share the CUs -- overlapped wall time, not a per-step cost. "
                      "MSM is integer-ALU-bound (254-bit Montgomery madds), not HBM-bound: see roofline_valu")}
+    # the next roof: the window tables are read by random 64 / 128-byte gathers, whose measured ceiling on this chip is
+    # far below the streaming peak (tools/ubench_affine_g2: ~2.2 TB/s, profiles/r03_ubench_affine_g2.txt)
+    extra["roofline_gather"] = {
+        "kernel": dom, "hbm_bytes_per_launch_by_counters": static["traffic"], "avg_launch_ms": round(iso, 4),
+        "achieved_gb_s": None if static["traffic"] is None else round(static["traffic"] / (iso * 1e-3) / 1e9, 1),
+        "ceiling_gb_s": GATHER_CEILING_GB_S, "ceiling_from": "profiles/r03_ubench_affine_g2.txt (random 64-128-byte gathers "
+        "from a 1.7-GB table, 1-2 waves/SIMD)",
+        "frac": None if static["traffic"] is None else round(static["traffic"] / (iso * 1e-3) / 1e9 / GATHER_CEILING_GB_S, 4),
+        "inputs_from": static["traffic_from"]}
+    # how much of a step is bucket accumulation: the isolated accumulate launches of one proof (4 G1 + 1 G2) over the
+    # measured step -- the rest of the step is tails, sorts, NTTs and whatever the in-flight proofs fail to overlap
+    if rep_other is not None:
+        both = {**{k: v["total_ms"] / v["calls"] for k, v in rep1.items()},
+                **{k: v["total_ms"] / v["calls"] for k, v in rep_other.items()}}
+        if "msm_accum_g1" in both and "msm_accum_g2" in both:
+            acc_ms = 4 * both["msm_accum_g1"] + both["msm_accum_g2"]
+            step_ms = dt / args.steps * 1e3 * (world if not shard else 1)     # per proof on THIS GPU
+            extra["accum_ms_per_proof"] = round(acc_ms, 4)
+            extra["overlap_efficiency"] = round(acc_ms / step_ms, 4)
     g1 = sum(v["total_ms"] for v in rep1.values()) / reps
     if grp == 1:
-        adds = n * W + 2 * (1 << (c - 1))     # bucket additions + running-sum reduction (one merged bucket set)
+        nwin = 254 // c + 1                   # W tables = nwin windows x (1 or 2) multiplier tables
+        h = 1 << (c - 1)
+        nbuckets = h if W == nwin else h // 2 + h // 8 + h // 32 + h // 64      # class bucket set with two tables
+        adds = n * nwin + 2 * nbuckets        # bucket additions + running-sum reduction (one merged bucket set)
+        extra["msm_buckets"] = nbuckets
         extra["msm_g1_adds_per_sec"] = round(adds / (g1 * 1e-3), 1)
         extra["msm_g1_pairs_per_sec"] = round(n / (g1 * 1e-3), 1)
         extra["msm_g1_ms"] = round(g1, 4)
@@ -397,7 +438,8 @@ def static_inputs(args, shard, dom):
     if args.log2n != 20 or shard:
         return out
     sha = lib_sha16()
-    for key, names in (("traffic", ("r03_pmc_hbm_traffic_2p20.json",)), ("valu", ("r03_valu_roofline_inputs.json",))):
+    for key, names in (("traffic", ("r04_pmc_hbm_traffic_2p20.json", "r03_pmc_hbm_traffic_2p20.json")),
+                       ("valu", ("r04_valu_roofline_inputs.json", "r03_valu_roofline_inputs.json"))):
         for name in names:
             path = os.path.join(ROOT, "profiles", name)
             try:
@@ -467,6 +509,8 @@ def finish_rank0(args, world, st):
     extra = st.get("extra", {})
     other = "value_witness_in_hbm" if args.witness == "host" else "value_witness_from_host"
     extra[other] = round(st["value_other"], 4)
+    extra["value_runs"] = st["value_runs"]
+    extra["value_is"] = f"median of {len(st['value_runs'])} timed regions of {args.steps} proofs each"
     extra["proof_latency_ms_single_in_flight"] = round(st["lat_ms"], 3)
     extra["proofs_in_flight_per_gpu"] = inflight
     extra["keys_resident_per_gpu"] = 1

@@ -104,8 +104,9 @@ size_t g16_points_count(const g16_points* pts);
  * from a matrix).  A set with at least G16_INF_COMPACT percent of them (environment, default 10) gets bucket entry
  * lists that leave them out, instead of paying a loop trip per (0,0) entry. */
 size_t g16_points_inf_count(const g16_points* pts);
-/* window size c and number of tables (= windows) chosen for this set; an MSM against it performs
- * count * ntables bucket additions + 2 * 2^(c-1) reduction additions */
+/* window size c and number of tables chosen for this set: W = 254 / c + 1 windows x 1 or 2 multiplier tables
+ * ([m][w][i] = 2^(c w + m) P_i).  An MSM against it performs count * W bucket additions + 2 reduction additions per
+ * bucket: 2^(c-1) buckets with one table per window, 0.67 * 2^(c-1) with two (the class bucket set, msm.cuh) */
 int32_t g16_points_info(const g16_points* pts, uint32_t* window_bits, uint32_t* ntables);
 /* sum_i scalars[i] * P_i over the whole registered set (scalars: g16_points_count elements);
  * flags = G16_SCALARS_MONT/STD | G16_SCALARS_DEVICE | G16_OUT_PARTIAL.  This is the call a prover makes
@@ -215,7 +216,13 @@ int32_t g16_prove_combine(g16_ctx* ctx, const g16_pkey* key, const void* partial
  *  one that wants to overlap two sharded proofs uses two contexts (nim_groth16_amd/distributed.py does).
  *  flags for _begin additionally: G16_NO_HOST_SYNC -- return without waiting for the coset vectors; the caller
  *  orders its exchange behind them through the context's stream (g16_ctx_set_stream: e.g. torch's current stream,
- *  on which the collective is then enqueued). */
+ *  on which the collective is then enqueued).
+ *  G16_NO_HOST_SYNC, the rules: (1) _begin honours it wherever the witness lives.  A HOST witness must then be in
+ *  pinned memory (otherwise the copy blocks anyway) and must stay untouched until the context's stream has passed the
+ *  copy -- e.g. until the matching _end or g16_prove_combine has returned, or an event recorded on that stream after
+ *  _begin has completed; the library does not wait for it.  (2) g16_prove_partials and _end honour it only together
+ *  with G16_OUT_DEVICE (a record written to host memory is not complete in stream order for the host); without
+ *  G16_OUT_DEVICE the flag is ignored and the call waits as usual. */
 int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags,
                                  uint32_t task_mask, void* d_task_out);
 int32_t g16_prove_partials_end(g16_ctx* ctx, const g16_pkey* key, const void* d_a1_slice, const void* d_b1_slice,

@@ -220,6 +220,63 @@ struct Fp29 {
     r.v[L - 1] = (uint32_t)acc;
     return r;
   }
+  // ---- chain PAIRS as asm statements (-DG16_F29_PAIR_ASM: the G2 accumulate kernel) ---------------------------------
+  // dot_pair below with its two lockstep chains written as multi-instruction asm statements (mac29p / mac29ps,
+  // ff29_mac.inc): the same instruction order as the pinned C++ chains, one hipcc s_nop per statement (<= 14
+  // multiply-adds) instead of one per product.  An asm statement takes <= 30 operands: <= 7 product pairs of VGPR
+  // factors, so a full column part (9 products per chain) is two statements.
+  template <int K, int OFF, int... I>
+  static FF_HD void pair_mul(uint64_t& acc, uint64_t& bcc, const fe29& a, const fe29& b, const fe29& c, const fe29& d,
+                             std::integer_sequence<int, I...>) {
+    mac29p(acc, bcc, a.v[col_lo<K>() + OFF + I]..., b.v[K - col_lo<K>() - OFF - I]..., c.v[col_lo<K>() + OFF + I]...,
+           d.v[K - col_lo<K>() - OFF - I]...);
+  }
+  template <int K>
+  static FF_HD void pair_term(uint64_t& acc, uint64_t& bcc, const fe29& a, const fe29& b, const fe29& c, const fe29& d) {
+    constexpr int n = col_cnt<K>(), first = n <= 7 ? n : (n + 1) / 2;
+    pair_mul<K, 0>(acc, bcc, a, b, c, d, std::make_integer_sequence<int, first>{});
+    if constexpr (n > first) pair_mul<K, first>(acc, bcc, a, b, c, d, std::make_integer_sequence<int, n - first>{});
+  }
+  template <int K, int... I>
+  static FF_HD void pair_red(uint64_t& acc, uint64_t& bcc, const uint32_t (&m)[L], const uint32_t (&n)[L],
+                             std::integer_sequence<int, I...>) {
+    mac29ps(acc, bcc, m[col_lo<K>() + I]..., n[col_lo<K>() + I]..., PL.v[K - col_lo<K>() - I]...);
+  }
+  template <int NP, int K>
+  static FF_HD void pair_col(uint64_t& acc, uint64_t& bcc, uint32_t (&m)[L], uint32_t (&n)[L], fe29& r0, fe29& r1,
+                             const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1, const fe29& a2,
+                             const fe29& b2, const fe29& a3, const fe29& b3, const fe29& c0, const fe29& d0,
+                             const fe29& c1, const fe29& d1, const fe29& c2, const fe29& d2, const fe29& c3,
+                             const fe29& d3) {
+    pair_term<K>(acc, bcc, a0, b0, c0, d0);
+    if constexpr (NP > 1) pair_term<K>(acc, bcc, a1, b1, c1, d1);
+    if constexpr (NP > 2) pair_term<K>(acc, bcc, a2, b2, c2, d2);
+    if constexpr (NP > 3) pair_term<K>(acc, bcc, a3, b3, c3, d3);
+    if constexpr (red_cnt<K>() > 0) pair_red<K>(acc, bcc, m, n, std::make_integer_sequence<int, red_cnt<K>()>{});
+    if constexpr (K < L) {
+      m[K] = ((uint32_t)acc * N0) & MASK;
+      n[K] = ((uint32_t)bcc * N0) & MASK;
+      acc += (uint64_t)m[K] * PL.v[0];
+      bcc += (uint64_t)n[K] * PL.v[0];
+    } else {
+      r0.v[K - L] = (uint32_t)acc & MASK;
+      r1.v[K - L] = (uint32_t)bcc & MASK;
+    }
+    acc >>= B;
+    bcc >>= B;
+  }
+  template <int NP, int... K>
+  static FF_HD void dot_pair_asm(fe29& r0, fe29& r1, const fe29& a0, const fe29& b0, const fe29& a1, const fe29& b1,
+                                 const fe29& a2, const fe29& b2, const fe29& a3, const fe29& b3, const fe29& c0,
+                                 const fe29& d0, const fe29& c1, const fe29& d1, const fe29& c2, const fe29& d2,
+                                 const fe29& c3, const fe29& d3, std::integer_sequence<int, K...>) {
+    uint32_t m[L], n[L];
+    uint64_t acc = 0, bcc = 0;
+    (pair_col<NP, K>(acc, bcc, m, n, r0, r1, a0, b0, a1, b1, a2, b2, a3, b3, c0, d0, c1, d1, c2, d2, c3, d3), ...);
+    r0.v[L - 1] = (uint32_t)acc;
+    r1.v[L - 1] = (uint32_t)bcc;
+  }
+
   // two independent NP-term dot products column by column in lockstep (r0 = sum a_j*b_j, r1 = sum c_j*d_j): with
   // the serial pins of F29_MAC each result is one multiply-add chain without join adds, and the two chains give
   // a wave the instruction-level parallelism that a single serial chain lacks at 2 waves/SIMD (G2 kernels)
@@ -228,6 +285,11 @@ struct Fp29 {
                              const fe29& a2, const fe29& b2, const fe29& a3, const fe29& b3, const fe29& c0,
                              const fe29& d0, const fe29& c1, const fe29& d1, const fe29& c2, const fe29& d2,
                              const fe29& c3, const fe29& d3) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_F29_PAIR_ASM)
+    dot_pair_asm<NP>(r0, r1, a0, b0, a1, b1, a2, b2, a3, b3, c0, d0, c1, d1, c2, d2, c3, d3,
+                     std::make_integer_sequence<int, 2 * L - 1>{});
+    return;
+#endif
     uint32_t m[L], n[L];
     uint64_t acc = 0, bcc = 0;
 #pragma unroll

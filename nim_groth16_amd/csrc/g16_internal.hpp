@@ -33,6 +33,7 @@ struct G16Env {
   int lanes_after_quotient = 0;   // G16_LANES_AFTER_QUOTIENT=1 (with the above): the witness accumulations wait for them
   int g1_batch = 0;               // G16_G1_BATCH=1: ONE batched launch sequence (blockIdx.y = MSM) for A1, B1, C1 on one stream
                                   // instead of one stream and one sequence per G1 MSM (prover.hip; measured slower)
+  int mtab = 2;                   // G16_MTAB=1: registered sets without the second multiplier table / class bucket set
   int chain_ch = 1;               // G16_CHAIN_CH=0: C1 and H1 as two MSMs instead of H1 continuing C1's bucket sums
 };
 const G16Env& g16_env();
@@ -194,7 +195,7 @@ struct ProfScope {
 
 
 // implemented in msm_g1.hip / msm_g2.hip / ntt.hip
-// table_c == 0: d_points = n affine points; table_c != 0: d_points = tables of a registered set
+// table_c == 0: d_points = n affine points; else g16_points::cfg() and d_points = the tables of that registered set
 int32_t g16_msm_device_g1(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
                           void* d_out_aff, void* d_out_acc, uint32_t table_c, const uint32_t* d_live = nullptr);
 int32_t g16_msm_device_g2(g16_ctx* ctx, const void* d_scalars, uint32_t flags, const void* d_points, size_t n,
@@ -241,9 +242,10 @@ G16_DECL_STAGES(g1)
 G16_DECL_STAGES(g2)
 int32_t g16_to29_device_g1(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out);
 int32_t g16_to29_device_g2(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out);
-int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
-int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables);
+int32_t g16_precompute_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, uint32_t mtab, void* d_tables);
+int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, uint32_t mtab, void* d_tables);
 uint32_t g16_pick_window_g1(size_t n);
+uint32_t g16_pick_mtab(uint32_t c);
 int32_t g16_on_curve_device_g1(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_first_bad);
 int32_t g16_on_curve_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t* d_first_bad);
 int32_t g16_fixed_base_device_g1(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
@@ -259,7 +261,9 @@ struct g16_points {
   int group = 1;          // 1: G1 (64-byte points), 2: G2 (128-byte points)
   size_t n = 0;
   uint32_t c = 0, nwin = 0;
-  void* d_tables = nullptr;  // nwin * n affine points, table-major
+  uint32_t mtab = 1;         // multiplier tables per window: 1, or 2 = {1, 2} with the class bucket set (msm.cuh)
+  uint32_t cfg() const { return c | (mtab << 8); }   // the `table_cfg` of g16_msm_sort / g16_msm_device_*
+  void* d_tables = nullptr;  // mtab * nwin * n affine points: [m][w][i] = 2^(c w + m) P_i
   uint32_t* d_live = nullptr;   // bitmap: bit i set <=> point i is not (0,0); ceil(n/32) words
   size_t n_inf = 0;             // points at infinity in the set
 };

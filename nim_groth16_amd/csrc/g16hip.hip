@@ -24,6 +24,7 @@ static G16Env read_env() {
   if (const char* v = getenv("G16_QUOTIENT_FIRST")) e.quotient_first = v[0] != '0';
   if (const char* v = getenv("G16_G1_BATCH")) e.g1_batch = v[0] != '0';
   if (const char* v = getenv("G16_CHAIN_CH")) e.chain_ch = v[0] != '0';
+  if (const char* v = getenv("G16_MTAB")) e.mtab = v[0] == '1' ? 1 : 2;
   if (const char* v = getenv("G16_NTT_TILE")) e.ntt_tile = atoi(v) == 1024 ? 1024 : atoi(v) == 4096 ? 4096 : 2048;
   if (const char* v = getenv("G16_MSM_SORT")) e.msm_sort = v[0];
   if (const char* v = getenv("G16_G1_LANES"))
@@ -277,14 +278,15 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
   h->n = n;
   h->c = g16_pick_window_g1(n);
   h->nwin = 254 / h->c + 1;
+  h->mtab = g16_pick_mtab(h->c);
   const size_t psz = group == 1 ? 64 : 128;
-  if ((size_t)h->nwin * n >= (size_t(1) << 31)) {
+  if ((size_t)h->mtab * h->nwin * n >= (size_t(1) << 31)) {
     delete h;
     ctx->err = "point set too large for 31-bit table indices";
     return G16_EINVAL;
   }
   if (n) {
-    hipError_t e = hipMalloc(&h->d_tables, (size_t)h->nwin * n * psz);   // packed reduced-radix entries: 64 / 128 B
+    hipError_t e = hipMalloc(&h->d_tables, (size_t)h->mtab * h->nwin * n * psz);   // packed reduced-radix entries: 64 / 128 B
     if (e != hipSuccess) {
       delete h;
       ctx->err = "hipMalloc(tables) failed";
@@ -299,8 +301,8 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
       d_src = ctx->stage_p.p;
     }
     if (!rc)
-      rc = group == 1 ? g16_precompute_device_g1(ctx, d_src, n, h->c, h->d_tables)
-                      : g16_precompute_device_g2(ctx, d_src, n, h->c, h->d_tables);
+      rc = group == 1 ? g16_precompute_device_g1(ctx, d_src, n, h->c, h->mtab, h->d_tables)
+                      : g16_precompute_device_g2(ctx, d_src, n, h->c, h->mtab, h->d_tables);
     // which points are (0,0): snarkjs keys hold the point at infinity for every wire absent from a matrix
     uint32_t n_inf = 0;
     if (!rc && hipMalloc((void**)&h->d_live, ((n + 31) / 32 + 1) * 4) != hipSuccess) rc = G16_ENOMEM;
@@ -358,7 +360,7 @@ extern "C" size_t g16_points_count(const g16_points* h) { return h ? h->n : 0; }
 extern "C" int32_t g16_points_info(const g16_points* h, uint32_t* window_bits, uint32_t* ntables) {
   if (!h) return G16_EINVAL;
   if (window_bits) *window_bits = h->c;
-  if (ntables) *ntables = h->nwin;
+  if (ntables) *ntables = h->nwin * h->mtab;
   return G16_OK;
 }
 
@@ -453,8 +455,8 @@ extern "C" int32_t g16_msm_points(g16_ctx* ctx, const g16_points* pts, const voi
   void* d_aff = partial ? nullptr : ctx->stage_o.p;
   void* d_acc = partial ? ctx->stage_o.p : nullptr;
   const uint32_t* live = g16_points_live_if_sparse(pts);
-  rc = pts->group == 1 ? g16_msm_device_g1(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c, live)
-                       : g16_msm_device_g2(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->c, live);
+  rc = pts->group == 1 ? g16_msm_device_g1(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->cfg(), live)
+                       : g16_msm_device_g2(ctx, d_s, flags, pts->d_tables, n, d_aff, d_acc, pts->cfg(), live);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_o.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -96,6 +96,18 @@ struct MsmBatch {
 // `live` (optional): bitmap over the pairs; a cleared bit drops the pair before its scalar is even read -- the entry
 // lists of point sets with many points at infinity ((0,0) for every wire absent from a matrix, curves.nim:95-107)
 // then hold only the points that can contribute.
+// ---- class bucket set of a registered point set with multiplier tables {1, 2} (MsmParams::mtab == 2) ---------------
+// A signed digit of magnitude t in [1, H], H = 2^(c-1), is served from the table of 2^(c w) P or of 2 * 2^(c w) P:
+//   t = 2^s * b,  s = ctz(t) & 1,  so that b = 4^z * u with u odd (an even power of two times an odd number),
+// and the bucket is b's, with the entry pointing into table s.  Only the b of that form are buckets: 2/3 of [1, H] --
+// the running-sum reduction (2 general additions per bucket, 8.6 % of a proof's instructions in round 3) shrinks by a
+// third for the same 13 accumulated entries per scalar.  Bucket order = (class z, v) with u = 2 v + 1: inside a class
+// the weights 4^z (2 v + 1) are an arithmetic progression, which is all the running sums need (msm_fold_classes).
+// Classes z = 0, 1, 2 hold t with ctz(t) < 6; the rest (t = 64 x) go unmultiplied to class X, weight 64 x.  Sizes
+// H/2, H/8, H/32, H/64: 43 slices of 2^(c-7) buckets.  Every bucket receives one or two digit values (u > H/2 or an
+// odd-length chain end: one), so bucket loads are 1x or 2x the load of the plain set -- like its two rounds of tasks.
+// (msm_class_bucket itself lives in msm_params.hpp: host and device code, and a CPU test, share it)
+
 template <class EMIT>
 __device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, const uint32_t* __restrict__ live, uint32_t i,
                                            const MsmParams& P, EMIT&& emit) {
@@ -110,7 +122,15 @@ __device__ __forceinline__ void msm_digits(const u256* __restrict__ scalars, con
     uint32_t neg = raw > half ? 1u : 0u;
     uint32_t mag = neg ? (1u << c) - raw : raw;
     carry = neg;
-    if (mag) emit(w, mag - 1, neg);
+    if (mag) {
+      if (P.mtab == 2) {   // (window + table selector, class bucket): the entry then indexes table [s][w]
+        uint32_t sel;
+        const uint32_t b = msm_class_bucket(mag, c, sel);
+        emit(w + sel * P.nwin, b, neg);
+      } else {
+        emit(w, mag - 1, neg);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 7; ++j) s.v[j] = __builtin_amdgcn_alignbit(s.v[j + 1], s.v[j], c);
     s.v[7] >>= c;
@@ -843,22 +863,86 @@ __global__ void __launch_bounds__(128, tail_waves<C>()) msm_fold_merged(const Ms
   }
 }
 
+// ---- K7'': fold for the class bucket set (MsmParams::mtab == 2, msm_class_bucket) --------------------------------
+// 43 slices of Ks = 2^log2ks buckets, reduced with slice-local weights l = 1..Ks (set_sum W_v, set_tot T_v): slices
+// 0..31 are class 0, 32..39 class 1, 40..41 class 2 (bucket weight 4^z (2 (sigma Ks + l - 1) + 1), sigma = slice
+// inside the class), slice 42 is class X (weight 64 l).  Hence
+//   S = sum_v y_v + 2 Ks * sum_v e_v T_v ,   y_v = 4^z (2 W_v - T_v)  (X: 64 W_v),   e_v = 4^z sigma  (X: 0; all < 32).
+// Wave 1 forms the y_v (one doubling, one addition, <= 5 more doublings per lane) and all-reduces them; wave 0 forms
+// sum e_v T_v as the sum over sigma >= 1 of the per-class suffix sums of T (segmented shuffle scan), scaled by 4^z per
+// lane, all-reduces, applies the log2(2 Ks) doublings cooperatively and finishes.
+template <class C>
+__global__ void __launch_bounds__(128, tail_waves<C>()) msm_fold_classes(const MsmBatch<C> B, uint32_t log2ks) {
+  tail_prio();
+  __shared__ typename C::Acc ysum;
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const typename C::Acc* __restrict__ set_sum = J.wsum;
+  const typename C::Acc* __restrict__ set_tot = J.wsum + 65;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // class, slice inside the class, first lane of the next class
+  const int z = lane < 32 ? 0 : lane < 40 ? 1 : lane < 42 ? 2 : 3;
+  const int first = z == 0 ? 0 : z == 1 ? 32 : z == 2 ? 40 : 42, end = z == 0 ? 32 : z == 1 ? 40 : z == 2 ? 42 : 43;
+  const bool live = lane < (int)MSM_CLASS_SLICES;
+  if (wave == 1) {
+    typename C::Acc y = live ? set_sum[lane] : C::acc_inf();
+    y = C::dbl(y);                                             // 2 W
+    if (live && z < 3) C::add(y, C::neg(set_tot[lane]));       // - T
+    const int nd = z == 0 ? 0 : z == 1 ? 2 : z == 2 ? 4 : 5;  // 4^z; X: 2 W -> 64 W
+#pragma unroll 1
+    for (int i = 0; i < 5; ++i) {
+      typename C::Acc d = C::dbl(y);
+      if (i < nd) y = d;
+    }
+    y = wave_allreduce<C>(y);
+    if (lane == 0) ysum = y;
+  }
+  typename C::Acc xs = C::acc_inf();
+  if (wave == 0) {
+    // inclusive suffix scan of T inside each class, then the suffixes of sigma >= 1, scaled by 4^z
+    typename C::Acc suf = (live && z < 3) ? set_tot[lane] : C::acc_inf();
+#pragma unroll 1
+    for (int d = 1; d < 32; d <<= 1) {
+      typename C::Acc other = wave_get_acc<C>(suf, (lane + d) & 63);
+      if (lane + d < end && z < 3) C::add(suf, other);
+    }
+    if (lane == first || z == 3 || !live) suf = C::acc_inf();   // sigma = 0 carries weight 0
+    const int nd = z == 1 ? 2 : z == 2 ? 4 : 0;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      typename C::Acc d = C::dbl(suf);
+      if (i < nd) suf = d;
+    }
+    xs = wave_allreduce<C>(suf);
+#pragma unroll 1
+    for (uint32_t i = 0; i < log2ks + 1; ++i) xs = dbl_coop<C>(xs);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    C::add(xs, ysum);
+    if (J.out_acc) *J.out_acc = xs;
+    if (J.out_aff) *J.out_aff = C::to_affine(xs);
+  }
+}
+
 // ---- registration-time precomputation:  table[w][i] = 2^(c w) * P_i  (affine), w = 0..nwin-1 ---------
 // One thread per point: c doublings per window, one inversion per stored point.  Runs once per circuit
 // (the reference loads ProverPoints once per zkey, zkey_types.nim:36-41); trades HBM capacity
 // (nwin x the point set) for the removal of the serial doubling chain from every MSM.
+// mtab == 2: a second set of tables [1][w][i] = 2 * 2^(c w) P_i behind the first (MsmParams::mtab)
 template <class C>
 __global__ void __launch_bounds__(MSM_BLOCK) msm_precompute(const typename C::Aff* __restrict__ points, uint32_t n,
-                                                            uint32_t c, uint32_t nwin,
+                                                            uint32_t c, uint32_t nwin, uint32_t mtab,
                                                             typename Ec29<C>::Tab* __restrict__ tables) {
   uint32_t i = blockIdx.x * MSM_BLOCK + threadIdx.x;
   if (i >= n) return;
   typename C::Aff p = points[i];
   tables[i] = Ec29<C>::tab_from_std(p);
   typename C::Acc acc = C::from_affine(p);
-  for (uint32_t w = 1; w < nwin; ++w) {
-    for (uint32_t k = 0; k < c; ++k) acc = C::dbl(acc);
-    tables[(size_t)w * n + i] = Ec29<C>::tab_from_std(C::to_affine(acc));
+  for (uint32_t w = 0; w < nwin; ++w) {
+    if (w) tables[(size_t)w * n + i] = Ec29<C>::tab_from_std(C::to_affine(acc));
+    acc = C::dbl(acc);
+    if (mtab == 2) tables[((size_t)nwin + w) * n + i] = Ec29<C>::tab_from_std(C::to_affine(acc));
+    for (uint32_t k = 1; k < c; ++k) acc = C::dbl(acc);
   }
 }
 

@@ -8,8 +8,9 @@ static u256 std_fp(uint32_t a7, uint32_t a6, uint32_t a5, uint32_t a4, uint32_t 
 int32_t g16_to29_device_g2(g16_ctx* ctx, hipStream_t st, const void* d_points, size_t n, void* d_out) {
   return to29_device<G2>(ctx, st, d_points, n, d_out);
 }
-int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
-  return precompute_device<G2>(ctx, d_points, n, c, d_tables);
+int32_t g16_precompute_device_g2(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, uint32_t mtab,
+                                 void* d_tables) {
+  return precompute_device<G2>(ctx, d_points, n, c, mtab, d_tables);
 }
 int32_t g16_fixed_base_device_g2(g16_ctx* ctx, void* d_table, bool ready, const void* d_s, uint32_t mont, size_t n,
                                  void* d_out) {

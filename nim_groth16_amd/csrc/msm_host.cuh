@@ -37,17 +37,23 @@ static uint32_t pick_window_cost(size_t n, bool merged, int forced, uint32_t cma
 }
 static uint32_t pick_window(size_t n) { return pick_window_cost(n ? n : 1, false, g16_env().msm_window, 16); }
 
-static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
+// table_cfg: 0 for a plain point array, else the window bits of a registered set | its multiplier tables << 8
+// (g16_points::cfg)
+static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_cfg) {
   MsmParams P;
+  const uint32_t table_c = table_cfg & 0xffu;
   P.n = (uint32_t)n;
   P.c = table_c ? table_c : pick_window(n);
   P.nwin = FR_BITS / P.c + 1;
   P.tables = table_c ? 1u : 0u;
-  P.nbuckets = P.tables ? (1u << (P.c - 1)) : (P.nwin << (P.c - 1));
+  P.mtab = table_c && (table_cfg >> 8) == 2 ? 2u : 1u;
+  P.nbuckets = P.tables ? msm_table_buckets(P.c, P.mtab) : (P.nwin << (P.c - 1));
   // segment length L: one accumulate task handles <= L entries.  A task is a serial chain of L mixed adds
   // (~23 us each with 4 waves per SIMD), so L also bounds the tail of the launch; ~1.25 x the mean bucket size
   // keeps most buckets in one segment, the rest get 1-2 short extra segments that msm_reduce1 absorbs.
-  size_t avg = ((size_t)n * P.nwin) / P.nbuckets + 1;
+  // (class bucket set: a bucket serves one or two digit values -- size the segment for the two-value buckets, or most
+  // of them are split: 112 instead of 121 proofs/s, profiles/r04_ab_mtab_seg.txt)
+  size_t avg = P.mtab == 2 ? ((size_t)n * P.nwin * 2) / (size_t(1) << (P.c - 1)) + 1 : ((size_t)n * P.nwin) / P.nbuckets + 1;
   P.seg = (uint32_t)(((avg + avg / 4 + 15) / 16) * 16);
   // few, long buckets (small windows / small point sets): cut them so that the launch still has ~64 k tasks --
   // a task is a serial chain, and 2^11 buckets of 1500 entries each would otherwise run as 2^11 threads
@@ -62,8 +68,8 @@ static MsmParams msm_params(size_t n, uint32_t flags, uint32_t table_c) {
 
 // ---- phase 1: scalars -> bucket arrangement (count, scan, scatter, extra-segment list) ---------------------
 static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scalars, uint32_t flags, size_t n,
-                               uint32_t table_c, g16_ctx::MsmSort& S, const uint32_t* d_live = nullptr) {
-  const MsmParams P = msm_params(n, flags, table_c);
+                               uint32_t table_cfg, g16_ctx::MsmSort& S, const uint32_t* d_live = nullptr) {
+  const MsmParams P = msm_params(n, flags, table_cfg);
   S.P = P;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -150,4 +156,7 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
 }
 
 static uint32_t pick_table_window(size_t n) { return pick_window_cost(n ? n : 1, true, g16_env().table_window, 22); }
+// multiplier tables of a registered set with window c: the 43 slices of 2^(c-7) buckets of the class bucket set must
+// be whole 256-bucket partitions of the sort
+static uint32_t pick_table_mtab(uint32_t c) { return g16_env().mtab == 2 && c >= 15 ? 2u : 1u; }
 

@@ -3,6 +3,7 @@
 #include "msm_host.cuh"
 
 uint32_t g16_pick_window_g1(size_t n) { return pick_table_window(n); }
+uint32_t g16_pick_mtab(uint32_t c) { return pick_table_mtab(c); }
 
 int32_t g16_msm_sort(g16_ctx* ctx, hipStream_t stream, const void* d_scalars, uint32_t flags, size_t n, uint32_t table_c,
                      g16_ctx::MsmSort& sort, const uint32_t* d_live) {
@@ -93,7 +94,7 @@ static int32_t msm_device(g16_ctx* ctx, int group, const void* d_scalars, uint32
   ctx->sort[0].narrow_tail = false;   // stand-alone MSM: nothing overlaps its tail, the short chain wins
   int32_t rc = msm_sort_device(ctx, ctx->stream, d_scalars, flags, n, table_c, ctx->sort[0], d_live);
   if (rc) return rc;
-  if (table_c == 0 && n) {   // plain point array: the accumulate kernel reads reduced-radix entries
+  if ((table_c & 0xffu) == 0 && n) {   // plain point array: the accumulate kernel reads reduced-radix entries
     const size_t esz = group == 1 ? 64 : 128;
     if ((rc = ensure(ctx, ctx->stage_p29, n * esz))) return rc;
     rc = group == 1 ? g16_to29_device_g1(ctx, ctx->stream, d_points, n, ctx->stage_p29.p)

@@ -56,7 +56,10 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams&
   // allow: 512 chunks (2^13 buckets) per slice at c = 20 -> 64 workgroups, one chunk per thread (G1) / two (G2).
   // G16_RED_SLICE = log2(chunks per slice) overrides it (experiments).
   uint32_t nsets = P.nwin, log2ks = 0;
-  if (P.tables) {
+  if (P.tables && P.mtab == 2) {   // class bucket set: 43 slices of 2^(c-7) buckets (msm_class_bucket)
+    nsets = MSM_CLASS_SLICES;
+    log2ks = P.c - 7;
+  } else if (P.tables) {
     const uint32_t want = 1u << (g16_env().red_slice_log2 ? g16_env().red_slice_log2 : 9);
     uint32_t cps = nchunks < want ? (uint32_t)nchunks : want;
     while (nchunks / cps > 64) cps <<= 1;
@@ -85,7 +88,9 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams&
     default:
       KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), dim3(nsets, ny), R2N, R2N * sizeof(typename C::Acc), B, cps);
   }
-  if (P.tables)
+  if (P.tables && P.mtab == 2)
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_classes<C>, dim3(1, ny), 128, 0, B, log2ks);
+  else if (P.tables)
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, dim3(1, ny), 128, 0, B, nsets, log2ks);
   else
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold<C>, dim3(1, ny), 64, 0, B, nsets, P.c);
@@ -112,10 +117,11 @@ static int32_t sum_partials_device(g16_ctx* ctx, const void* d_parts, uint32_t c
 }
 
 template <class C>
-static int32_t precompute_device(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, void* d_tables) {
+static int32_t precompute_device(g16_ctx* ctx, const void* d_points, size_t n, uint32_t c, uint32_t mtab,
+                                 void* d_tables) {
   const uint32_t nwin = FR_BITS / c + 1;
   KLAUNCH(ctx, "msm_precompute", msm_precompute<C>, (uint32_t)((n + MSM_BLOCK - 1) / MSM_BLOCK), MSM_BLOCK, 0,
-          (const typename C::Aff*)d_points, (uint32_t)n, c, nwin, (typename Ec29<C>::Tab*)d_tables);
+          (const typename C::Aff*)d_points, (uint32_t)n, c, nwin, mtab, (typename Ec29<C>::Tab*)d_tables);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }

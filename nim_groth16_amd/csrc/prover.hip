@@ -239,7 +239,7 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
           hipStreamSynchronize(ctx->stream) != hipSuccess)
         TRY(G16_EHIP);
       k->deadB = dead;
-      if (!dead || dead * 100 < (size_t)g16_env().inf_compact_pct * nw) {   // dense: share the witness sort
+      if (!dead || (size_t)dead * 100 < (size_t)g16_env().inf_compact_pct * nw) {   // dense: share the witness sort
         (void)hipFree(k->liveB);
         k->liveB = nullptr;
       }
@@ -374,7 +374,7 @@ static int32_t upload_witness(g16_ctx* ctx, const g16_pkey* k, const void* witne
 // instead of from infinity, and the pair needs one bucket reduction (reduce1 / reduce2 / fold) instead of two.  The
 // C1 slot of the record stays at infinity.  G16_CHAIN_CH=0 restores two separate MSMs.
 static bool chain_c_into_h(const g16_pkey* k) {
-  return g16_env().chain_ch && k->w_hi > k->w_lo && k->h_hi > k->h_lo && k->C1->c == k->H1->c;
+  return g16_env().chain_ch && k->w_hi > k->w_lo && k->h_hi > k->h_lo && k->C1->cfg() == k->H1->cfg();
 }
 
 // The four MSMs that consume the witness (A1, B1, B2, C1: prover.nim:282, 288, 294, 302) on the lane streams.  The
@@ -404,15 +404,15 @@ static int32_t launch_witness_sorts(g16_ctx* ctx, const g16_pkey* k, uint32_t fl
   const u256* d_wr = b.d_w + k->w_lo;
   HIPCHK(ctx, hipStreamWaitEvent(L[0].stream, ctx->ev_a, 0));
   for (auto& srt : ctx->sort) srt.narrow_tail = true;   // proofs overlap their MSM tails with other work (msm_stage.cuh)
-  if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[0]))) return rc;
+  if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->cfg(), ctx->sort[0]))) return rc;
   if (k->liveA)   // A1 with many (0,0) points: its own arrangement, behind the shared one
-    if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->c, ctx->sort[2], k->liveA))) return rc;
+    if ((rc = g16_msm_sort(ctx, L[0].stream, d_wr, wflags, nw, k->A1->cfg(), ctx->sort[2], k->liveA))) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_b, L[0].stream));
   // B1 / B2 with many (0,0) points: their own arrangement of the witness (live pairs only), built on B2's lane
   // while lane 0 arranges the full witness
   if (k->liveB) {
     HIPCHK(ctx, hipStreamWaitEvent(L[1].stream, ctx->ev_a, 0));
-    if ((rc = g16_msm_sort(ctx, L[1].stream, d_wr, wflags, nw, k->B2->c, ctx->sort[3], k->liveB))) return rc;
+    if ((rc = g16_msm_sort(ctx, L[1].stream, d_wr, wflags, nw, k->B2->cfg(), ctx->sort[3], k->liveB))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_b2, L[1].stream));
   }
   return G16_OK;
@@ -459,7 +459,7 @@ static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const ProveB
 static int32_t launch_h_sort(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice) {
   const size_t nh = k->h_hi - k->h_lo;
   ctx->sort[1].narrow_tail = true;
-  return nh ? g16_msm_sort(ctx, ctx->stream, d_qs_slice, G16_SCALARS_MONT, nh, k->H1->c, ctx->sort[1]) : G16_OK;
+  return nh ? g16_msm_sort(ctx, ctx->stream, d_qs_slice, G16_SCALARS_MONT, nh, k->H1->cfg(), ctx->sort[1]) : G16_OK;
 }
 static int32_t launch_h_and_collect(g16_ctx* ctx, const g16_pkey* k, const u256* d_qs_slice, uint32_t flags,
                                     const ProveBufs& b, void* out_partials, bool sorted = false) {

@@ -197,7 +197,6 @@ class ShardedProver:
         if len(self._inflight) >= self.depth:
             done = self._finish_oldest()
         slot = self._slot(self._head)
-        self._head = (self._head + 1) % self.depth
         self._buffers(slot)
         slot.job = (r, s)
         try:
@@ -206,13 +205,16 @@ class ShardedProver:
             else:
                 self.pkey.prove_partials(witness, mont=mont, device=device, out=slot.mine.data_ptr(), ctx=slot.ctx)
         except BaseException:
-            # a failed exchange leaves the witness lanes of `begin` running: drain them before the caller goes on
-            # (any later call on the context would do the same: include/g16hip.h)
+            # A failed begin / exchange may leave the witness lanes of `begin` running and a proof pending on the
+            # context.  g16_ctx_synchronize would wait for the main stream only and keep the pending proof; a call that
+            # enters the context the ordinary way drains EVERY lane and cancels it (include/g16hip.h) -- the self-test
+            # is the cheapest one.  The slot stays free: `_head` has not moved.
             slot.job, slot.works = None, []
             try:
-                slot.ctx.synchronize()
+                slot.ctx.selftest()
             finally:
                 raise
+        self._head = (self._head + 1) % self.depth
         self._inflight.append(slot)
         return done
 

@@ -2,6 +2,7 @@
 // against the oracle on a machine without a GPU.  Not part of the product library.
 #include "../../nim_groth16_amd/csrc/ec29.cuh"
 #include "../../nim_groth16_amd/csrc/pairing.cuh"
+#include "../../nim_groth16_amd/csrc/msm_params.hpp"
 #include <cstring>
 #include <vector>
 using namespace g16;
@@ -51,6 +52,29 @@ static void tree29(const void* pts, int n, void* out) {
 }
 
 extern "C" {
+// the class bucket set of registered point sets with two multiplier tables (msm_params.hpp): every digit magnitude
+// t in [1, 2^(c-1)] must land in a bucket whose weight (from the class layout, restated here) times 2^s is t, every
+// bucket must be hit once or twice, and none may lie outside the set.  -> 0, or the first offending t
+uint32_t shim_class_buckets_check(uint32_t c) {
+  const uint32_t h = 1u << (c - 1), nb = msm_table_buckets(c, 2);
+  std::vector<uint8_t> hits(nb, 0);
+  auto weight = [&](uint32_t id) -> uint64_t {
+    if (id < h / 2) return 2ull * id + 1;
+    if (id < h / 2 + h / 8) return 4ull * (2ull * (id - h / 2) + 1);
+    if (id < h / 2 + h / 8 + h / 32) return 16ull * (2ull * (id - h / 2 - h / 8) + 1);
+    return 64ull * (id - h / 2 - h / 8 - h / 32 + 1);
+  };
+  for (uint32_t t = 1; t <= h; ++t) {
+    uint32_t s = 9;
+    const uint32_t id = msm_class_bucket(t, c, s);
+    if (id >= nb || s > 1 || (weight(id) << s) != t) return t;
+    if (++hits[id] > 2) return t;
+  }
+  for (uint32_t id = 0; id < nb; ++id)
+    if (!hits[id]) return 0x80000000u | id;
+  return nb == h / 2 + h / 8 + h / 32 + h / 64 && nb % (MSM_CLASS_SLICES) == 0 && nb / MSM_CLASS_SLICES == (1u << (c - 7)) ? 0 : 1;
+}
+
 // op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 dbl 6 div2 7 inv 8 from_mont 9 to_mont ; field: 0 Fp 1 Fr
 void shim_field_op(int field, int op, const void* a, const void* b, void* r) {
   u256 x = ld<u256>(a), y = ld<u256>(b), z;

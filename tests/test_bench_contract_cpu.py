@@ -64,7 +64,8 @@ def test_bench_source_emits_the_same_keys():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for k in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
               '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"',
-              '"frac"', '"cores"', '"kind"', '"sample"', '"roofline_valu"', '"frac_mix"', '"frac_multiply_only"'):
+              '"frac"', '"cores"', '"kind"', '"sample"', '"roofline_valu"', '"frac_mix"', '"frac_multiply_only"',
+              '"roofline_gather"', '"value_runs"', '"accum_ms_per_proof"', '"overlap_efficiency"'):
         assert k in src, k
 
 
@@ -88,3 +89,5 @@ def test_accumulate_hot_loops_keep_their_instruction_budget():
     assert not any(op.startswith("scratch_store") for op in g1), "the G1 accumulate loop spills"
     g2 = V.hot_loop_mix(V.code_object(os.path.join(csrc, "msm_g2_accum.o")), r"msm_accum")
     assert 4300 <= g2["v_mad_u64_u32"] <= 4400 and sum(c for op, c in g2.items() if op.startswith("v_")) <= 6700
+    assert g2.get("s_nop", 0) <= 300, g2.get("s_nop")        # 280: chain pairs as asm statements (956 with pinned C++ pairs)
+    assert not any(op.startswith("scratch_store") for op in g2), "the G2 accumulate loop spills"

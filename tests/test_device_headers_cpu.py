@@ -207,3 +207,12 @@ def test_pairing_formulas(shim):
     # infinity on either side -> 1
     shim.shim_pairing(1, o.g1_to_bytes(o.INF_G1), o.g2_to_bytes(o.GEN2), buf)
     assert _gt_from_bytes(buf.raw) == o._f12_one()
+
+
+def test_class_bucket_set_of_two_multiplier_tables(shim):
+    """msm_class_bucket (msm_params.hpp, shared by the sort kernels): every signed-digit magnitude of a window maps to
+    a bucket of the class set whose weight times the table's multiplier is that magnitude; every bucket is used by one
+    or two magnitudes; the set is 43 slices of 2^(c-7) buckets."""
+    shim.shim_class_buckets_check.restype = ctypes.c_uint32
+    for c in (15, 17, 20, 22):
+        assert shim.shim_class_buckets_check(c) == 0, c

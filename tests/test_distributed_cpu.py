@@ -123,9 +123,13 @@ def test_sharded_proof_world2_gloo():
 # ---- the pipeline of ShardedProver (submit / collect, depth 2) with a CPU stand-in for the sharded key -------------
 class _FakeCtx:
     device = None                      # "no GPU": ShardedProver keeps its buffers in host memory
+    selftests = 0
 
     def synchronize(self):
         pass
+
+    def selftest(self):                # an ordinary context entry: drains every lane, cancels a pending begin
+        self.selftests += 1
 
     def set_stream(self, ptr):
         pass
@@ -254,3 +258,37 @@ def test_sharded_pipeline_world2_gloo_depth2():
     for (_, out, single) in outs:
         assert out == want
         assert single == want[0]
+
+
+def test_failed_begin_leaves_the_pipeline_consistent():
+    """a begin that raises must not consume a slot -- `_head` stays, the slot's context is quiesced through
+    an ordinary entry (which cancels the pending proof), and the proofs submitted before and after come out in order."""
+    from nim_groth16_amd.distributed import ShardedProver
+    from nim_groth16_amd.zkey_types import GrothHeader, ZKey
+    oz, r, s = _setup()
+    zk = ZKey(header=GrothHeader("bn128", 1, oz.nvars, oz.npubs, oz.domainSize, oz.logDomainSize))
+    log = []
+    key = _FakeKey(oz, 0, 1, log)
+    real_begin, calls = key.prove_partials_begin, []
+
+    def flaky_begin(*a, **kw):
+        calls.append(1)
+        if len(calls) == 2:
+            raise RuntimeError("injected begin failure")
+        return real_begin(*a, **kw)
+    key.prove_partials_begin = flaky_begin
+    sp = ShardedProver(zk, 0, 1, pkey=key, depth=2, ctx_factory=_FakeCtx)
+    wb = I.fr_mont_bytes(o.TOY_WITNESS)
+    rb, sb = o.fr_to_mont_bytes(r), o.fr_to_mont_bytes(s)
+    assert sp.submit(wb, True, rb, sb) is None
+    with pytest.raises(RuntimeError):
+        sp.submit(wb, True, sb, rb)                      # would have gone into slot 1
+    assert sp._head == 1 and len(sp._inflight) == 1 and sp._slots[1].ctx.selftests == 1 and sp._slots[1].job is None
+    assert sp.submit(wb, True, sb, rb) is None           # the same slot again
+    out = sp.collect()
+    want = []
+    for (mr, ms) in [(r, s), (s, r)]:
+        ref = o.generate_proof_with_mask(oz, o.TOY_WITNESS, mr, ms)
+        want.append((o.g1_to_bytes(ref.pi_a), o.g2_to_bytes(ref.pi_b), o.g1_to_bytes(ref.pi_c)))
+    assert out == want
+    sp.close()

@@ -116,7 +116,7 @@ struct Container {
     int fd = open(path, O_RDONLY);
     if (fd < 0) die(std::string("cannot open ") + path);
     struct stat st;
-    fstat(fd, &st);
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) die(std::string("cannot stat ") + path);
     const uint8_t* b = (const uint8_t*)mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (b == MAP_FAILED) die("mmap failed");
     size_t n = st.st_size;
@@ -127,13 +127,13 @@ struct Container {
     if (ver != version) die("unexpected container version");
     size_t pos = 12;
     for (uint32_t i = 0; i < nsec; ++i) {
-      if (pos + 12 > n) die("truncated file");
+      if (n - pos < 12) die("truncated file");
       uint32_t id;
       uint64_t len;
       memcpy(&id, b + pos, 4);
       memcpy(&len, b + pos + 4, 8);
       pos += 12;
-      if (pos + len > n) die("truncated section");
+      if (len > n - pos) die("truncated section");   // (not pos + len > n: a crafted 64-bit length would wrap)
       if (!sec.count(id)) sec[id] = Section{b + pos, (size_t)len};
       pos += len;
     }
@@ -192,6 +192,7 @@ struct ZkeyFile {
     alpha1 = p, beta1 = p + 64, beta2 = p + 128, gamma2 = p + 256, delta1 = p + 384, delta2 = p + 448;
     ic = points(3, 64, (size_t)npubs + 1);
     Section s4 = zk.get(4);
+    if (s4.len < 4) die("coefficient section too short");
     const uint32_t ncoeffs = u32(s4.p);
     if (s4.len != 4 + (size_t)ncoeffs * 44) die("unexpected coefficient section length");
     coeffs.resize(ncoeffs);
