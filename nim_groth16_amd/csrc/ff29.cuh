@@ -47,22 +47,46 @@ struct fe29 {
 
 #include "ff29_mac.inc"
 
-struct Fp29 {
+struct Limbs29 {
+  uint32_t v[9];
+};
+// the two BN254 fields in this radix.  PL: the modulus; N0 = -m^-1, PINV0 = m^-1 (mod 2^29); ONE = 2^261, C_IN = 2^266
+// (x*2^256 -> x*2^261), C_OUT = 2^256 (x*2^261 -> x*2^256), all mod m.
+struct Fp29Params {
+  static constexpr uint32_t N0 = 0x4866389u, PINV0 = 0x1b799c77u;
+  static constexpr Limbs29 PL = {{0x187cfd47u, 0x10460b6u, 0x1c72a34fu, 0x2d522d0u, 0x1585d978u, 0x2db40c0u,
+                                  0xa6e141u, 0xe5c2634u, 0x30644eu}};
+  static constexpr Limbs29 ONE = {{0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x14c0419u, 0xaa36fb9u, 0x1d4240ceu,
+                                   0x11d54c07u, 0x52ac7a8u, 0xdc836u}};
+  static constexpr Limbs29 C_IN = {{0x13349ca1u, 0x1a5d84a8u, 0xa3e5cacu, 0x100249e0u, 0x12b951e8u, 0xe92d304u,
+                                    0x14cb95b3u, 0x41b9d3du, 0x58003u}};
+  static constexpr Limbs29 C_OUT = {{0x58f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu,
+                                     0x1cbd99bau, 0x183340fbu, 0xe0a77u}};
+};
+// the scalar field r (the NTT butterflies, ntt29.cuh)
+struct Fr29Params {
+  static constexpr uint32_t N0 = 0xfffffffu, PINV0 = 0x10000001u;
+  static constexpr Limbs29 PL = {{0x10000001u, 0x1f0fac9fu, 0xe5c2450u, 0x7d090f3u, 0x1585d283u, 0x2db40c0u,
+                                  0xa6e141u, 0xe5c2634u, 0x30644eu}};
+  static constexpr Limbs29 ONE = {{0xfffff57u, 0x1ea70ab4u, 0x52c068bu, 0x17504f49u, 0xaa8075bu, 0x1d4240ceu,
+                                   0x11d54c07u, 0x52ac7a8u, 0xdc836u}};
+  static constexpr Limbs29 C_IN = {{0xfffead7u, 0x1d5444f4u, 0x4438aa5u, 0x3b4d096u, 0x134c84dau, 0xe92d304u,
+                                    0x14cb95b3u, 0x41b9d3du, 0x58003u}};
+  static constexpr Limbs29 C_OUT = {{0xffffffbu, 0x4b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu, 0x11b7bc3cu,
+                                     0x1cbd99bau, 0x183340fbu, 0xe0a77u}};
+};
+
+template <class PR>
+struct Field29 {
   static constexpr int B = 29, L = 9;
   static constexpr uint32_t MASK = (1u << B) - 1;
-  static constexpr uint32_t N0 = 0x4866389u;      // -p^-1 mod 2^29
-  static constexpr uint32_t PINV0 = 0x1b799c77u;  //  p^-1 mod 2^29
-  struct Limbs {
-    uint32_t v[9];
-  };
-  static constexpr Limbs PL = {{0x187cfd47u, 0x10460b6u, 0x1c72a34fu, 0x2d522d0u, 0x1585d978u, 0x2db40c0u,
-                                0xa6e141u, 0xe5c2634u, 0x30644eu}};
-  static constexpr Limbs ONE = {{0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x14c0419u, 0xaa36fb9u, 0x1d4240ceu,
-                                 0x11d54c07u, 0x52ac7a8u, 0xdc836u}};  // 2^261 mod p
-  static constexpr Limbs C_IN = {{0x13349ca1u, 0x1a5d84a8u, 0xa3e5cacu, 0x100249e0u, 0x12b951e8u, 0xe92d304u,
-                                  0x14cb95b3u, 0x41b9d3du, 0x58003u}};  // 2^266 mod p: x*2^256 -> x*2^261
-  static constexpr Limbs C_OUT = {{0x58f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu,
-                                   0x1cbd99bau, 0x183340fbu, 0xe0a77u}};  // 2^256 mod p: x*2^261 -> x*2^256
+  static constexpr uint32_t N0 = PR::N0;        // -m^-1 mod 2^29
+  static constexpr uint32_t PINV0 = PR::PINV0;  //  m^-1 mod 2^29
+  using Limbs = Limbs29;
+  static constexpr Limbs PL = PR::PL;
+  static constexpr Limbs ONE = PR::ONE;      // 2^261 mod m
+  static constexpr Limbs C_IN = PR::C_IN;    // 2^266 mod m: x*2^256 -> x*2^261
+  static constexpr Limbs C_OUT = PR::C_OUT;  // 2^256 mod m: x*2^261 -> x*2^256
 
   // limbs of MULT*p with LIFT units borrowed from every higher limb into the one below ("borrow form"):
   // same value, but limbs 0..7 >= LIFT*(2^29-1), so that  a + K - b  stays non-negative limb by limb
@@ -480,5 +504,7 @@ struct Fp29 {
   // any normalized value < 13p
   static FF_HD u256 to_std(const fe29& a) { return relimb(canon<1>(mul(a, constant(C_OUT)))); }
 };
+using Fp29 = Field29<Fp29Params>;
+using Fr29 = Field29<Fr29Params>;
 
 }  // namespace g16
