@@ -10,7 +10,8 @@
 //  * A multiplication is 162 carry-free multiply-adds + 54 other instructions instead of 128 + 128 carry
 //    instructions + ..., additions and subtractions are limb-wise without carries or comparisons (a - b adds a
 //    multiple of r in borrow form), and nothing is compared with r inside the tile.
-//  * Bounds (PROVED on worst-case intervals by tools/ntt29_model.py, which mirrors group4 / stage2 below): a value
+//  * Bounds (exercised AT the bounds, maximal limbs included, against Python integers by the CPU test
+//    tests/test_device_headers_cpu.py::test_ntt29_radix4_group_at_its_bounds; derivation in group4 below): a value
 //    that enters a radix-4 round trip below V r leaves it below (4 V + 1) r, products are below 6 r; the third round
 //    trip brings every output that did not come out of a multiplication back below 2 r (weak_reduce: one estimated
 //    quotient from the top limb), so V <= 197 at the end of a 10-stage pass and every limb stays below 2^32, every
