@@ -202,11 +202,22 @@ __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* ctr, uint32_t key) {
 // 1024 threads x 4 scalars: the pass is a chain of dependent LDS atomics and scattered 8-byte stores per thread, and a
 // 2^20-scalar sort has only 256 tiles -- one workgroup per CU -- so the workgroup is as wide as it gets (16 waves per
 // CU hide that latency; rounds 1-2 ran 256 threads x 16 scalars = ONE wave per SIMD)
+// Low bucket bits sorted inside a partition (bucket_hist / bucket_place: one thread per low value).  Round 4: 9 instead
+// of 8 -- half as many partitions (688 for the class set of c = 20), hence half as many (tile, partition) runs that
+// part_pass<true> keeps open at once: 32 tiles per XCD x 1376 runs x one active 128-byte line were 5.6 MB against a
+// 4-MB L2, and lines left the L2 half written (WRITE_SIZE 3.4 x the record bytes); 688 runs are 2.8 MB.
+constexpr int BS_LOG = 9;
+constexpr int BS_LOW = 1 << BS_LOG;
 constexpr int PART_BLOCK = 1024;
 constexpr int PART_PER_THREAD = 4;
 constexpr int PART_TILE = PART_BLOCK * PART_PER_THREAD;  // scalars per workgroup
 constexpr int PART_MAX = 8192;                           // max partitions (LDS histogram, 32 KB)
 
+// tile of a partition pass: XCD x takes a contiguous range of tiles, so that neighbouring tiles -- whose (tile,
+// partition) runs of tmp records share cache lines at their ends -- mostly write through the same L2
+__device__ __forceinline__ uint32_t part_tile_of_block(uint32_t bid, uint32_t ntiles) {
+  return (ntiles & 7u) ? bid : (bid & 7u) * (ntiles >> 3) + (bid >> 3);
+}
 template <bool SCATTER>
 static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __restrict__ scalars,
                                                                const uint32_t* __restrict__ live, MsmParams P,
@@ -214,7 +225,7 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
                                                                uint32_t* __restrict__ tile_hist,
                                                                uint2* __restrict__ tmp) {
   __shared__ uint32_t hist[PART_MAX];
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = part_tile_of_block(blockIdx.x, ntiles);
   for (uint32_t p = threadIdx.x; p < nparts; p += PART_BLOCK)
     hist[p] = SCATTER ? tile_hist[(size_t)p * ntiles + tile] : 0u;   // SCATTER: exclusive base of (part, tile)
   __syncthreads();
@@ -225,7 +236,7 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
       msm_digits(scalars, live, i, P, [&](uint32_t w, uint32_t k, uint32_t neg) {
         uint32_t part = (P.tables ? 0u : (w << hi_bits)) | (k >> lo_bits);
         uint32_t pos = lds_rank_add(hist, part);
-        if (SCATTER) tmp[pos] = make_uint2((k & lo_mask) | (neg << 8), P.tables ? w * P.n + i : i);
+        if (SCATTER) tmp[pos] = make_uint2((k & lo_mask) | (neg << BS_LOG), P.tables ? w * P.n + i : i);
       });
     }
   }
@@ -239,28 +250,46 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
 // separate workgroups: bucket_hist counts the low bits per slice, bucket_place derives count[]/offset[] from
 // the slice histograms and writes the final entries.
 constexpr int BS_SPLIT = 8;
+// Which (partition, slice) a workgroup of bucket_hist / bucket_place takes.  Workgroups are dealt round robin over the 8
+// XCDs (block b -> XCD b % 8), each with its own L2: with the plain order part = b / 8 the eight slices of a partition
+// -- which scatter 4-byte entries into the SAME 40-KB output range -- sat on eight different XCDs, and every 128-byte
+// line left eight L2s as a partial write (WRITE_SIZE 5.3 x the entry bytes, profiles/r03_pmc_hbm_traffic_2p20.json).
+// This order gives all slices of a partition the same b % 8, so that one L2 merges the line.  Speed / traffic only:
+// any bijection is correct.
+__device__ __forceinline__ void bs_block(uint32_t bid, uint32_t nparts, uint32_t& part, uint32_t& q) {
+  if (BS_SPLIT == 8 && (nparts & 7u) == 0) {
+    const uint32_t j = bid >> 3;
+    part = ((j >> 3) << 3) | (bid & 7u);
+    q = j & 7u;
+  } else {
+    part = bid / BS_SPLIT;
+    q = bid % BS_SPLIT;
+  }
+}
 __device__ __forceinline__ void bs_slice(uint32_t start, uint32_t end, uint32_t q, uint32_t& lo, uint32_t& hi) {
   const uint32_t len = end - start;
   lo = start + (uint32_t)(((uint64_t)len * q) / BS_SPLIT);
   hi = start + (uint32_t)(((uint64_t)len * (q + 1)) / BS_SPLIT);
 }
-static __global__ void __launch_bounds__(256) bucket_hist(const uint2* __restrict__ tmp,
+static __global__ void __launch_bounds__(BS_LOW) bucket_hist(const uint2* __restrict__ tmp,
                                                           const uint32_t* __restrict__ part_base, uint32_t ntiles,
                                                           uint32_t nparts, const uint32_t* __restrict__ total,
                                                           uint32_t* __restrict__ slice_hist) {
-  __shared__ uint32_t hist[256];
-  const uint32_t part = blockIdx.x / BS_SPLIT, q = blockIdx.x % BS_SPLIT, tid = threadIdx.x;
+  __shared__ uint32_t hist[BS_LOW];
+  uint32_t part, q;
+  bs_block(blockIdx.x, nparts, part, q);
+  const uint32_t tid = threadIdx.x;
   const uint32_t start = part_base[(size_t)part * ntiles];
   const uint32_t end = part + 1 < nparts ? part_base[(size_t)(part + 1) * ntiles] : total[0];
   uint32_t lo, hi;
   bs_slice(start, end, q, lo, hi);
   hist[tid] = 0;
   __syncthreads();
-  for (uint32_t j = lo + tid; j < hi; j += 256) lds_rank_add(hist, tmp[j].x & 0xffu);
+  for (uint32_t j = lo + tid; j < hi; j += BS_LOW) lds_rank_add(hist, tmp[j].x & (uint32_t)(BS_LOW - 1));
   __syncthreads();
-  slice_hist[(size_t)blockIdx.x * 256 + tid] = hist[tid];
+  slice_hist[((size_t)part * BS_SPLIT + q) * BS_LOW + tid] = hist[tid];
 }
-// `fused` (lo_bits == 8: one partition = one 256-bucket block of the size-order permutation): the q == 0 workgroup of
+// `fused` (lo_bits == BS_LOG: one partition = one PERM_BLOCK-bucket block of the size-order permutation): the q == 0 workgroup of
 // every partition holds the final bucket counts in registers anyway, so it also does what rounds 1-2 ran five more
 // launches for -- the extra-segment bookkeeping of split buckets (xoff[], heavy list; split buckets are rare, so
 // their range of extra-segment slots comes from one global atomic each instead of a device-wide scan) and the size
@@ -268,7 +297,7 @@ static __global__ void __launch_bounds__(256) bucket_hist(const uint2* __restric
 constexpr int PERM_BINS = 256;   // size classes of the bucket-order permutation (perm_hist / perm_scatter below)
 // extra segments of a bucket of cnt entries cut into segments of L: max(ceil(cnt / L) - 1, 0)
 __device__ __forceinline__ uint32_t extra_segs(uint32_t cnt, uint32_t L) { return cnt > L ? (cnt - 1) / L : 0u; }
-static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restrict__ tmp,
+static __global__ void __launch_bounds__(BS_LOW) bucket_place(const uint2* __restrict__ tmp,
                                                            const uint32_t* __restrict__ part_base, uint32_t ntiles,
                                                            uint32_t nparts, const uint32_t* __restrict__ total,
                                                            const uint32_t* __restrict__ slice_hist, MsmParams P,
@@ -278,24 +307,26 @@ static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restri
                                                            uint32_t* __restrict__ xoff, uint32_t* __restrict__ heavy,
                                                            uint32_t* __restrict__ info, uint32_t* __restrict__ ghist,
                                                            uint32_t* __restrict__ blk_base) {
-  __shared__ uint32_t cur[256];
+  __shared__ uint32_t cur[BS_LOW];
   __shared__ uint32_t szh[PERM_BINS];
-  const uint32_t part = blockIdx.x / BS_SPLIT, q = blockIdx.x % BS_SPLIT, tid = threadIdx.x;
+  uint32_t part, q;
+  bs_block(blockIdx.x, nparts, part, q);
+  const uint32_t tid = threadIdx.x;
   const uint32_t start = part_base[(size_t)part * ntiles];
   const uint32_t end = part + 1 < nparts ? part_base[(size_t)(part + 1) * ntiles] : total[0];
   // bucket totals over all slices, and the part of each bucket that belongs to earlier slices
   uint32_t mine = 0, before = 0;
 #pragma unroll
   for (int k = 0; k < BS_SPLIT; ++k) {
-    uint32_t h = slice_hist[((size_t)part * BS_SPLIT + k) * 256 + tid];
+    uint32_t h = slice_hist[((size_t)part * BS_SPLIT + k) * BS_LOW + tid];
     mine += h;
     if ((uint32_t)k < q) before += h;
   }
-  // exclusive scan of the 256 bucket totals (Hillis-Steele in LDS)
+  // exclusive scan of the bucket totals (Hillis-Steele in LDS)
   cur[tid] = mine;
-  szh[tid] = 0;
+  if (tid < PERM_BINS) szh[tid] = 0;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
+  for (int d = 1; d < BS_LOW; d <<= 1) {
     uint32_t add = (int)tid >= d ? cur[tid - d] : 0u;
     __syncthreads();
     cur[tid] += add;
@@ -324,16 +355,16 @@ static __global__ void __launch_bounds__(256) bucket_place(const uint2* __restri
     if (part == nparts - 1 && tid == 0) offset[P.nbuckets] = end;
   }
   __syncthreads();
-  if (q == 0 && fused) {
+  if (q == 0 && fused && tid < PERM_BINS) {
     const uint32_t m = szh[tid];
     blk_base[(size_t)part * PERM_BINS + tid] = m ? atomicAdd(&ghist[tid], m) : 0u;
   }
   uint32_t lo, hi;
   bs_slice(start, end, q, lo, hi);
-  for (uint32_t j = lo + tid; j < hi; j += 256) {
+  for (uint32_t j = lo + tid; j < hi; j += BS_LOW) {
     uint2 e = tmp[j];
-    uint32_t pos = lds_rank_add(cur, e.x & 0xffu);
-    entries[pos] = e.y | (((e.x >> 8) & 1u) << 31);
+    uint32_t pos = lds_rank_add(cur, e.x & (uint32_t)(BS_LOW - 1));
+    entries[pos] = e.y | (((e.x >> BS_LOG) & 1u) << 31);
   }
 }
 
@@ -490,12 +521,12 @@ static __global__ void __launch_bounds__(MSM_BLOCK) msm_make_extra(const uint32_
 // (~70 % lane efficiency at avg 32).  perm[] lists the buckets by descending min(count, 255), so the 64
 // lanes of a wave get (nearly) equal trip counts.  Two small kernels: per-block LDS histogram + one global
 // atomic per (block, size class) to reserve a range, then ranks from LDS atomics.
-constexpr int PERM_BLOCK = 256;
+constexpr int PERM_BLOCK = BS_LOW;   // = one partition of the fused sort (bucket_place writes blk_base per partition)
 static __global__ void __launch_bounds__(PERM_BLOCK) perm_hist(const uint32_t* __restrict__ count, uint32_t nb,
                                                                uint32_t* __restrict__ ghist,
                                                                uint32_t* __restrict__ blk_base) {
   __shared__ uint32_t h[PERM_BINS];
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < PERM_BINS) h[threadIdx.x] = 0;
   __syncthreads();
   uint32_t b = blockIdx.x * PERM_BLOCK + threadIdx.x;
   if (b < nb) {
@@ -503,8 +534,10 @@ static __global__ void __launch_bounds__(PERM_BLOCK) perm_hist(const uint32_t* _
     atomicAdd(&h[c < PERM_BINS - 1 ? c : PERM_BINS - 1], 1u);
   }
   __syncthreads();
-  uint32_t mine = h[threadIdx.x];
-  blk_base[(size_t)blockIdx.x * PERM_BINS + threadIdx.x] = mine ? atomicAdd(&ghist[threadIdx.x], mine) : 0u;
+  if (threadIdx.x < PERM_BINS) {
+    uint32_t mine = h[threadIdx.x];
+    blk_base[(size_t)blockIdx.x * PERM_BINS + threadIdx.x] = mine ? atomicAdd(&ghist[threadIdx.x], mine) : 0u;
+  }
 }
 static __global__ void __launch_bounds__(PERM_BLOCK) perm_scatter(const uint32_t* __restrict__ count, uint32_t nb,
                                                                   const uint32_t* __restrict__ ghist,
@@ -512,19 +545,22 @@ static __global__ void __launch_bounds__(PERM_BLOCK) perm_scatter(const uint32_t
                                                                   uint32_t* __restrict__ perm) {
   __shared__ uint32_t start[PERM_BINS];   // first position of size class v (descending order)
   __shared__ uint32_t cur[PERM_BINS];
-  // suffix sums of the 256-bin histogram: start[v] = sum_{v' > v} ghist[v']
-  start[threadIdx.x] = ghist[threadIdx.x];
-  cur[threadIdx.x] = 0;
+  // suffix sums of the 256-bin histogram: start[v] = sum_{v' > v} ghist[v']   (threads >= PERM_BINS only wait)
+  const bool bin = threadIdx.x < PERM_BINS;
+  if (bin) {
+    start[threadIdx.x] = ghist[threadIdx.x];
+    cur[threadIdx.x] = 0;
+  }
   __syncthreads();
   for (int d = 1; d < PERM_BINS; d <<= 1) {
-    uint32_t add = (int)threadIdx.x + d < PERM_BINS ? start[threadIdx.x + d] : 0u;
+    uint32_t add = bin && (int)threadIdx.x + d < PERM_BINS ? start[threadIdx.x + d] : 0u;
     __syncthreads();
-    start[threadIdx.x] += add;
+    if (bin) start[threadIdx.x] += add;
     __syncthreads();
   }
-  uint32_t incl = start[threadIdx.x];
+  uint32_t incl = bin ? start[threadIdx.x] : 0u;
   __syncthreads();
-  start[threadIdx.x] = incl - ghist[threadIdx.x];
+  if (bin) start[threadIdx.x] = incl - ghist[threadIdx.x];
   __syncthreads();
   uint32_t b = blockIdx.x * PERM_BLOCK + threadIdx.x;
   if (b < nb) {

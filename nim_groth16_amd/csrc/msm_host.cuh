@@ -83,15 +83,17 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
                o_entries = take((size_t)P.n * P.nwin * 4), o_xseg = take((size_t)P.max_extra * 8),
                o_perm = take(nb * 4), o_ghist = take(PERM_BINS * 4),
                o_blk = take(((nb + PERM_BLOCK - 1) / PERM_BLOCK) * PERM_BINS * 4);
-  // partition sort (see msm.cuh): low bits <= 8, partitions = nwin << hi_bits
-  const uint32_t lo_bits = P.c - 1 < 8 ? P.c - 1 : 8;
+  // partition sort (see msm.cuh): low bits <= BS_LOG (as many as divide the bucket count: the class set of a
+  // registered set is 43 * 2^(c-7) buckets), partitions = nwin << hi_bits
+  uint32_t lo_bits = P.c - 1 < (uint32_t)BS_LOG ? P.c - 1 : (uint32_t)BS_LOG;
+  while (lo_bits && (P.nbuckets & ((1u << lo_bits) - 1))) --lo_bits;
   const uint32_t nparts = P.nbuckets >> lo_bits;
   const uint32_t ptiles = (P.n + PART_TILE - 1) / PART_TILE;
   const bool use_part = nparts <= PART_MAX && g16_env().msm_sort != 'a';
   const size_t nth = (size_t)nparts * ptiles;
   const size_t o_thist = take(use_part ? nth * 4 : 4), o_tmp = take(use_part ? (size_t)P.n * P.nwin * 8 : 8),
                o_tiles2 = take(((nth + SCAN_TILE - 1) / SCAN_TILE) * 8 + 8),
-               o_shist = take(use_part ? (size_t)nparts * BS_SPLIT * 256 * 4 : 4);
+               o_shist = take(use_part ? (size_t)nparts * BS_SPLIT * BS_LOW * 4 : 4);
   int32_t rc = ensure(ctx, S.buf, o);
   if (rc) return rc;
   char* ws = (char*)S.buf.p;
@@ -112,9 +114,9 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
   S.tiles2 = (uint2*)(ws + o_tiles2);
   S.slice_hist = (uint32_t*)(ws + o_shist);
   const auto* scalars = (const u256*)d_scalars;
-  // lo_bits == 8: bucket_place also produces xoff / heavy / the size histogram (see msm.cuh); count[] and offset[] are
-  // fully written by it, so the partition path clears only the two small counter blocks
-  const bool fused = use_part && lo_bits == 8;
+  // lo_bits == BS_LOG: bucket_place also produces xoff / heavy / the size histogram (see msm.cuh); count[] and
+  // offset[] are fully written by it, so the partition path clears only the two small counter blocks
+  const bool fused = use_part && lo_bits == (uint32_t)BS_LOG;
   if (!use_part) HIPCHK(ctx, hipMemsetAsync(ws + o_count, 0, o_offset - o_count, st));  // count + cursor are adjacent
   HIPCHK(ctx, hipMemsetAsync(S.info, 0, 64, st));
   HIPCHK(ctx, hipMemsetAsync(S.ghist, 0, PERM_BINS * 4, st));
@@ -129,9 +131,9 @@ static int32_t msm_sort_device(g16_ctx* ctx, hipStream_t st, const void* d_scala
     KLAUNCH_ON(ctx, st, "msm_scan", scan1_apply, nt2, SCAN_BLOCK, 0, S.tile_hist, (uint32_t)nth, S.tiles2);
     KLAUNCH_ON(ctx, st, "msm_part_scatter", part_pass<true>, ptiles, PART_BLOCK, 0, scalars, d_live, P, lo_bits, nparts,
                ptiles, S.tile_hist, S.tmp);
-    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_hist, nparts * BS_SPLIT, 256, 0, S.tmp, S.tile_hist, ptiles, nparts,
+    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_hist, nparts * BS_SPLIT, BS_LOW, 0, S.tmp, S.tile_hist, ptiles, nparts,
                S.info + 8, S.slice_hist);
-    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_place, nparts * BS_SPLIT, 256, 0, S.tmp, S.tile_hist, ptiles, nparts,
+    KLAUNCH_ON(ctx, st, "msm_bucket_sort", bucket_place, nparts * BS_SPLIT, BS_LOW, 0, S.tmp, S.tile_hist, ptiles, nparts,
                S.info + 8, S.slice_hist, P, lo_bits, S.count, S.offset, S.entries, fused ? 1u : 0u, S.xoff, S.heavy,
                S.info, S.ghist, S.blk_base);
   } else {
