@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_2p20_final.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_2p20_final.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -30,27 +30,32 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["inputs_from"]["kernels_sha16"] == d["kernels_sha16"] == d["roofline_valu"]["inputs_from"]["kernels_sha16"]
     v = d["roofline_valu"]
     assert "g16_profile_clock" in v["clock_source"] and 1.5 < v["sustained_clock_ghz"] < 2.6 and 0.8 < v["frac_mix"] < 1.0
+    # round 4: the median of repeated timed regions, the share of a step that is bucket accumulation, the gather roof
+    assert len(d["value_runs"]) >= 5 and sorted(d["value_runs"])[len(d["value_runs"]) // 2] == d["value"]
+    assert 0.5 < d["overlap_efficiency"] < 1.0 and abs(d["overlap_efficiency"] - d["accum_ms_per_proof"] / d["ms_per_step"]) < 1e-3
+    g = d["roofline_gather"]
+    assert g["hbm_bytes_per_launch_by_counters"] == r["traffic"] and 0.2 < g["frac"] < 1.0
 
 
 def test_valu_roofline_inputs_are_consistent():
-    """profiles/r03_valu_roofline_inputs.json (tools/valu_roofline.py) -> bench.py's roofline_valu object"""
+    """profiles/r04_valu_roofline_inputs.json (tools/valu_roofline.py) -> bench.py's roofline_valu object"""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    inp = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_roofline_inputs.json")))
+    inp = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_roofline_inputs.json")))
     assert inp["kernels_sha16"] and inp["git"]
     # the committed counters belong to the library in the tree (when it is built): a kernel edit must come with a new
     # counter pass (tools/profile_session.sh), or bench.py will rightly report nulls
     from nim_groth16_amd._lib import device_code_sha16, lib_path
     if os.path.exists(lib_path()) and inp["kernels_sha16"] != device_code_sha16():
         import warnings
-        warnings.warn("profiles/r03_valu_roofline_inputs.json was measured on another build: bench.py will report "
+        warnings.warn("profiles/r04_valu_roofline_inputs.json was measured on another build: bench.py will report "
                       "nulls for the counter-derived roofline inputs until tools/profile_session.sh is re-run")
     k = inp["kernels"]["msm_accum_g1"]
     assert 0.5 < k["mad_u64_share_of_valu"] < 0.7 and 3.5 < k["mix_issue_cycles_per_inst"] < 4.5
     assert 4.0 < inp["issue_cycles"]["v_mad_u64_u32"] < 5.0 and 1.8 < k["sustained_clock_ghz"] < 2.5
     r = bench.valu_roofline("msm_accum_g1", k["duration_us"] / 1e3, k["sustained_clock_ghz"],
-                            {"valu": inp, "valu_from": {"file": "profiles/r03_valu_roofline_inputs.json"}})
+                            {"valu": inp, "valu_from": {"file": "profiles/r04_valu_roofline_inputs.json"}})
     for key in ("bound", "achieved_ms", "valu_wave_insts_per_launch", "sustained_clock_ghz", "bound_ms_mix", "frac_mix",
                 "bound_ms_multiply_only", "frac_multiply_only"):
         assert key in r, key
