@@ -189,7 +189,10 @@ int32_t g16_prove(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32
                   const void* mask_s, g16_proof* out);
 /* The two halves of g16_prove, for a proof sharded over several GPUs (one g16_ctx + one sharded key per GPU):
  *  g16_prove_partials: buildABC + quotient (replicated) and the five MSMs over this key's index ranges;
- *      writes G16_PARTIALS_BYTES = 768 bytes: XYZZ accumulators A1 | B1 | B2 (256 B) | H1 | C1.
+ *      writes G16_PARTIALS_BYTES = 768 bytes: XYZZ accumulators A1 | B1 | B2 (256 B) | H1 | C1.  The record is
+ *      opaque: accumulators are not canonical (the addition order inside a bucket is not fixed), and when the C1 and
+ *      H1 sets share their bucket set the H1 slot holds H1 + C1 and the C1 slot infinity (pi_c needs only the sum,
+ *      prover.nim:301-302).  Only g16_prove_combine gives records a meaning; it accepts any mix of them.
  *      flags: G16_SCALARS_MONT/STD | G16_SCALARS_DEVICE (witness in HBM) | G16_OUT_DEVICE (output in HBM).
  *  g16_prove_combine: `count` gathered records (rank order; e.g. from an RCCL all-gather) are summed per MSM
  *      -- the `res += sync pending[k]` of msm.nim:117-119 across GPUs -- and the mask algebra of
