@@ -76,6 +76,7 @@ KNOBS = [
     {"G16_NTT_FIELD": "29"},                                    # reduced-radix NTT passes (ntt29.cuh; round 4)
     {"G16_MTAB": "1"},                                          # one table per window, plain bucket set (rounds 1-3)
     {"G16_TABLE_WINDOW": "15"},                                 # the smallest window with the class bucket set
+    {"G16_TABLE_WINDOW": "17", "G16_MSM_SORT": "a"},           # class bucket set through the global-atomic sort
     {"G16_TABLE_WINDOW": "16", "G16_MSM_SEG": "8", "G16_G1_BATCH": "1"},   # class set + split buckets + batched tails
     {"G16_CHAIN_CH": "1", "G16_MSM_SEG": "8", "G16_INF_COMPACT": "0"},   # the chain across split buckets and own sorts
 ]
