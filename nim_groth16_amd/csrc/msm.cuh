@@ -9,9 +9,11 @@
 //          offsets, split-bucket segment list, buckets ordered by size.  (msm_count / msm_scatter / scan_* / perm_hist:
 //          the global-atomic variant, used when the partition count exceeds the LDS histogram and by G16_MSM_SORT=a)
 //   accum  msm_accum      one thread per bucket *segment* (<= L entries): XYZZ += affine table point, 9x29 field
-//   heavy  msm_heavy[_small]  buckets that were split in >1 segment: LDS tree / one thread
+//   heavy  msm_heavy      buckets that were split in >1 segment: one thread (few segments) / LDS tree (many)
 //   reduce msm_reduce1/2  sum_k k*B_k: 16-bucket chunk running sums, then per slice an LDS suffix scan + tree
-//   fold   msm_fold[_merged]  slices (registered sets) or windows (Horner) -> one point; canonical affine on request
+//   fold   msm_fold_classes / msm_fold_merged (registered sets: slices of the class / plain bucket set) or msm_fold
+//          (windows, Horner) -> one point; canonical affine on request
+// Every stage from accum on takes up to MSM_BATCH_MAX jobs per launch (blockIdx.y).
 //
 // Load balance: work is cut by *entries*, not by buckets -- a circom witness puts ~30 % of all
 // scalars in bucket (w=0, d=1); that bucket becomes ~N/L segments handled by N/L threads.
@@ -377,7 +379,7 @@ constexpr int SCAN_ITEMS = 8;                       // per thread
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;  // 2048 buckets per workgroup
 
 // split buckets with at least this many extra segments are combined by a workgroup (msm_heavy), the others by
-// one thread each (msm_heavy_small)
+// one thread each (phase 1 of msm_heavy)
 constexpr uint32_t HEAVY_MIN = 12;
 
 __device__ __forceinline__ uint2 block_excl_scan2(uint2 v, uint2* total) {
