@@ -251,23 +251,13 @@ static __global__ void __launch_bounds__(PART_BLOCK) part_pass(const u256* __res
 // A partition can be arbitrarily large (skewed scalars), so each one is cut into BS_SPLIT slices handled by
 // separate workgroups: bucket_hist counts the low bits per slice, bucket_place derives count[]/offset[] from
 // the slice histograms and writes the final entries.
-constexpr int BS_SPLIT = 8;
 // Which (partition, slice) a workgroup of bucket_hist / bucket_place takes.  Workgroups are dealt round robin over the 8
 // XCDs (block b -> XCD b % 8), each with its own L2: with the plain order part = b / 8 the eight slices of a partition
 // -- which scatter 4-byte entries into the SAME 40-KB output range -- sat on eight different XCDs, and every 128-byte
 // line left eight L2s as a partial write (WRITE_SIZE 5.3 x the entry bytes, profiles/r03_pmc_hbm_traffic_2p20.json).
 // This order gives all slices of a partition the same b % 8, so that one L2 merges the line.  Speed / traffic only:
 // any bijection is correct.
-__device__ __forceinline__ void bs_block(uint32_t bid, uint32_t nparts, uint32_t& part, uint32_t& q) {
-  if (BS_SPLIT == 8 && (nparts & 7u) == 0) {
-    const uint32_t j = bid >> 3;
-    part = ((j >> 3) << 3) | (bid & 7u);
-    q = j & 7u;
-  } else {
-    part = bid / BS_SPLIT;
-    q = bid % BS_SPLIT;
-  }
-}
+// (bs_block itself lives in msm_params.hpp: a CPU test checks that it is a bijection)
 __device__ __forceinline__ void bs_slice(uint32_t start, uint32_t end, uint32_t q, uint32_t& lo, uint32_t& hi) {
   const uint32_t len = end - start;
   lo = start + (uint32_t)(((uint64_t)len * q) / BS_SPLIT);

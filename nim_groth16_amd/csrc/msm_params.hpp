@@ -28,6 +28,18 @@ constexpr uint32_t MSM_CLASS_SLICES = 32 + 8 + 2 + 1;   // slices of 2^(c-7) buc
 #else
 #define G16_MSMP_HD inline
 #endif
+// (partition, slice) of workgroup `bid` of bucket_hist / bucket_place; see msm.cuh
+constexpr int BS_SPLIT = 8;
+G16_MSMP_HD void bs_block(uint32_t bid, uint32_t nparts, uint32_t& part, uint32_t& q) {
+  if (BS_SPLIT == 8 && (nparts & 7u) == 0) {
+    const uint32_t j = bid >> 3;
+    part = ((j >> 3) << 3) | (bid & 7u);
+    q = j & 7u;
+  } else {
+    part = bid / BS_SPLIT;
+    q = bid % BS_SPLIT;
+  }
+}
 // digit magnitude t in [1, 2^(c-1)] -> (class bucket, table selector s): t = 2^s * weight(bucket); see msm.cuh
 G16_MSMP_HD uint32_t msm_class_bucket(uint32_t t, uint32_t c, uint32_t& s) {
   const uint32_t tz = (uint32_t)__builtin_ctz(t), h = 1u << (c - 1);

@@ -53,6 +53,23 @@ static void tree29(const void* pts, int n, void* out) {
 }
 
 extern "C" {
+// bs_block (msm_params.hpp): every (partition, slice) exactly once, and all slices of a partition on one XCD (same
+// block index modulo 8) whenever the partition count is a multiple of 8.  -> 0 if so
+uint32_t shim_bs_block_check(uint32_t nparts) {
+  std::vector<uint8_t> seen((size_t)nparts * BS_SPLIT, 0);
+  std::vector<int> xcd(nparts, -1);
+  for (uint32_t b = 0; b < nparts * BS_SPLIT; ++b) {
+    uint32_t part = ~0u, q = ~0u;
+    bs_block(b, nparts, part, q);
+    if (part >= nparts || q >= (uint32_t)BS_SPLIT || seen[(size_t)part * BS_SPLIT + q]++) return 1 + b;
+    if ((nparts & 7u) == 0) {
+      if (xcd[part] < 0) xcd[part] = (int)(b & 7u);
+      else if (xcd[part] != (int)(b & 7u)) return 1 + b;
+    }
+  }
+  return 0;
+}
+
 // ntt29.cuh, the radix-4 group of the reduced-radix NTT: x[4] = values (standard integers below V * r, 36 bytes each
 // as nine 29-bit limbs, normalized by the caller), t[3] = twiddles (canonical Montgomery-256 form), out: the four
 // outputs as canonical standard integers (the 2^-261 of the products undone: data stay in whatever form they came)

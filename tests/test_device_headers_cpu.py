@@ -277,3 +277,12 @@ def test_ntt29_radix4_group_at_its_bounds(shim):
                     buf = ctypes.create_string_buffer(32)
                     shim.shim_ntt29_store_any((ctypes.c_uint32 * 9)(*out[9 * i:9 * i + 9]), buf)
                     assert int.from_bytes(buf.raw, "little") == want[i] % R
+
+
+def test_sort_block_order_is_a_bijection_and_keeps_a_partition_on_one_xcd(shim):
+    """bs_block (msm_params.hpp): the workgroup order of bucket_hist / bucket_place -- every (partition, slice) once;
+    with a partition count that is a multiple of 8 all eight slices of a partition share the block index modulo 8 (the
+    XCD the workgroup is dealt to), so one L2 merges the partition's output lines."""
+    shim.shim_bs_block_check.restype = ctypes.c_uint32
+    for nparts in (8, 688, 1376, 2752, 1, 3, 10, 43):
+        assert shim.shim_bs_block_check(nparts) == 0, nparts
