@@ -20,7 +20,10 @@ struct G16Env {
   int table_window = 0;    // G16_TABLE_WINDOW 5..22: window bits of registered point sets
   int msm_seg = 0;         // G16_MSM_SEG      8..4096: accumulate segment length
   char msm_sort = 0;       // G16_MSM_SORT     'a': atomic histogram/scatter instead of the partition sort
-  int g1_lanes[3] = {0, 2, 3};   // G16_G1_LANES  lanes of the A1 / B1 / C1 MSMs (three digits from {0,2,3})
+  int g1_lanes[3] = {3, 2, 0};   // G16_G1_LANES  lanes of the A1 / B1 / C1 MSMs (three digits from {0,2,3}).  C1 goes first,
+                                 // on the sort's own lane: the H accumulation continues C1's bucket sums, so a late C1
+                                 // delays the last chain of the proof (single-proof latency 11.2 -> 10.8 ms, same
+                                 // throughput: profiles/r04_ab_g1_lanes.txt; rounds 1-3: 0, 2, 3)
   char stream_prio[7] = "lhllln";   // G16_STREAM_PRIO  six characters from {h, n, l}
   int red_slice_log2 = 0;  // G16_RED_SLICE    log2 of the chunks per reduce2 slice of a merged bucket set (8..11)
   int inf_compact_pct = 10;   // G16_INF_COMPACT  point sets with at least this percentage of (0,0) points get their own

@@ -65,7 +65,7 @@ extern "C" int32_t g16_ctx_create(int32_t device, g16_ctx** out) {
   return G16_OK;
 }
 
-// Stream priorities.  Index 0..4 = lanes (0: witness sort + A1, 1: B2, 2: B1, 3: C1, 4: spare), 5 = main stream
+// Stream priorities.  Index 0..4 = lanes (0: witness sort + C1, 1: B2, 2: B1, 3: A1, 4: spare), 5 = main stream
 // (buildABC, quotient NTTs, H).  Default "lhllln" (G2 high, main normal, G1 lanes low): the G2 MSM has the longest
 // latency chain of a proof; prioritising it lets its reduce/fold tail overlap the G1 accumulations of this and
 // of the other in-flight proofs (measured with 3 proofs in flight: 78 proofs/s flat, 90 "lhlllh", 97 "lhllln").
