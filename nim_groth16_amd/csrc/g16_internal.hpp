@@ -40,8 +40,22 @@ struct G16Env {
                                   // (bit-identical; measured: passes -5 %, fused last pass +18 %, proofs/s -1.6 %)
   int mtab = 2;                   // G16_MTAB=1: registered sets without the second multiplier table / class bucket set
   int chain_ch = 1;               // G16_CHAIN_CH=0: C1 and H1 as two MSMs instead of H1 continuing C1's bucket sums
+  int tail_quad = -1;             // G16_TAIL_QUAD = 0 | 1: reduce2 / fold with one lane / a cooperating quad per slot (msm.cuh;
+                                  // unset: quads for small bucket sets, msm_stage.cuh)
+  int red_chunk = 0;              // G16_RED_CHUNK = 2 | 4 | 8 | 16: buckets per thread of msm_reduce1 (unset: msm_red_chunk)
+  int g2_first = -1;              // G16_G2_FIRST = 0 | 1 | 2: A1 and B1 (2: C1 too) accumulate after B2 (unset: 1 for small shards,
+                                  // prover.hip)
 };
 const G16Env& g16_env();
+
+// Buckets per thread of the first reduction stage (msm_reduce1).  16 keeps the chunk records (two accumulators per
+// chunk) and reduce2's work small where the reduction is throughput: a 2^20 proof's 352 k buckets.  A small bucket set
+// (a shard's point sets, a small MSM) is a latency chain on a mostly empty GPU: with 4 the chain of reduce1 is 8
+// additions instead of 32 and reduce2, run wide, pays 2 more scan steps (a G2 addition is ~20 us of wave time).
+inline uint32_t msm_red_chunk(const g16::MsmParams& P) {
+  if (g16_env().red_chunk) return (uint32_t)g16_env().red_chunk;
+  return P.nbuckets <= (1u << 17) ? 4u : 16u;
+}
 
 struct ProfEntry {
   const char* name;
@@ -80,7 +94,7 @@ struct g16_ctx {
   };
   MsmSort sort[4];   // 0: witness (all pairs)  1: H scalars  2: witness, A1's live pairs  3: witness, B1/B2's live pairs
   MsmLane lane[5];
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_q = nullptr, ev_b2 = nullptr, ev_c = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_q = nullptr, ev_b2 = nullptr, ev_c = nullptr, ev_g2 = nullptr;
   Buf stage_s;   // staged scalars (host-pointer API)
   Buf stage_p;   // staged points
   Buf stage_p29; // the same points as reduced-radix entries (one-shot MSMs; registered sets keep their own tables)

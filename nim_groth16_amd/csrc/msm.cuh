@@ -690,11 +690,11 @@ __global__ void __launch_bounds__(heavy_block<C>(), tail_waves<C>()) msm_heavy(c
 
 // ---- K6: bucket reduction  S_w = sum_{k=1}^{K} k * B_{w,k},  K = 2^(c-1) -----------------------------
 // stage 1: thread per chunk of RC consecutive buckets: R_j = sum B_k, A_j = sum (k - j*RC) B_k
-constexpr int RED_CHUNK = 16;
+// (RC = msm_red_chunk, g16_internal.hpp: 16, or 4 for small bucket sets)
 // A job that continues another MSM's bucket sums (MsmJob::init): a bucket without entries of its own still
 // holds the other MSM's sum, so every bucket is added (infinity is skipped inside the addition).
 template <class C>
-__global__ void __launch_bounds__(MSM_BLOCK, tail_waves<C>()) msm_reduce1(const MsmBatch<C> B, uint32_t nbuckets) {
+__global__ void __launch_bounds__(MSM_BLOCK, tail_waves<C>()) msm_reduce1(const MsmBatch<C> B, uint32_t nbuckets, uint32_t rc) {
   tail_prio();
   using E = Ec29<C>;   // running sums in the reduced-radix field; the chunk sums leave in the standard layout
   const MsmJob<C>& J = B.job[blockIdx.y];
@@ -702,10 +702,11 @@ __global__ void __launch_bounds__(MSM_BLOCK, tail_waves<C>()) msm_reduce1(const 
   const uint32_t* __restrict__ offset = J.offset;
   const bool always = J.init != nullptr;
   uint32_t j = blockIdx.x * MSM_BLOCK + threadIdx.x;
-  uint32_t b0 = j * RED_CHUNK;
+  uint32_t b0 = j * rc;
   if (b0 >= nbuckets) return;
   typename E::Acc run = E::acc_inf(), acc = E::acc_inf();
-  for (int k = RED_CHUNK - 1; k >= 0; --k) {
+#pragma unroll 1
+  for (int k = (int)rc - 1; k >= 0; --k) {
     uint32_t b = b0 + k;
     if (b < nbuckets && (always || offset[b + 1] != offset[b])) E::add(run, partial[b]);
     E::add(acc, run);
@@ -722,7 +723,8 @@ __global__ void __launch_bounds__(MSM_BLOCK, tail_waves<C>()) msm_reduce1(const 
 // few doublings, and ONE LDS tree adds the v_t.  The whole kernel is a latency chain of ~40 group operations,
 // so the block is as wide as the register budget allows (BLOCK = 512 for G1, 256 for G2).
 template <class C, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, tail_waves<C>()) msm_reduce2(const MsmBatch<C> B, uint32_t chunks_per_window) {
+__global__ void __launch_bounds__(BLOCK, tail_waves<C>()) msm_reduce2(const MsmBatch<C> B, uint32_t chunks_per_window,
+                                                                      uint32_t rc) {
   tail_prio();
   extern __shared__ __align__(16) unsigned char smem[];
   typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
@@ -760,7 +762,7 @@ __global__ void __launch_bounds__(BLOCK, tail_waves<C>()) msm_reduce2(const MsmB
   // v_t = RC * (per * suffix_t + wsum_t) + sumA_t
   typename C::Acc v = (threadIdx.x >= 1 && lo < M) ? C::mul_small(incl, per) : C::acc_inf();
   C::add(v, wsum);
-  v = C::mul_small(v, RED_CHUNK);
+  v = C::mul_small(v, rc);
   C::add(v, sumA);
   __syncthreads();
   typename C::Acc tot = block_sum<C, BLOCK>(v, sh);
@@ -805,6 +807,146 @@ __device__ __forceinline__ typename C::Acc dbl_coop(const typename C::Acc& p) {
   // a b - c d on every lane (c = 0 on lanes 1, 2: the plain product through the same code path)
   const E l3 = F::mulsub(sel3(role, m, v, w), sel3(role, F::sub(s, x3), p.zz, p.zzz), role == 0 ? w : F::zero(), p.y);
   return typename C::Acc{x3, wave_get(l3, 0), wave_get(l3, 1), wave_get(l3, 2)};
+}
+
+// ---- quad-cooperative group operations for the latency chains ------------------------------------------------------
+// reduce2 and the folds are chains of DEPENDENT group operations run by a handful of waves: one addition on one lane
+// is bound by the issue rate of its wave (~4.5 us G1, ~20 us G2) while most of the GPU idles.  The 14 multiplications
+// of add-2008-s fall into four levels of mutually independent products:
+//   level 1:  u1 = x1 zz2     u2 = x2 zz1     s1 = y1 zzz2    s2 = y2 zzz1          (p = u2 - u1, r = s2 - s1)
+//   level 2:  pp = p^2        rr = r^2        z12 = zz1 zz2   z123 = zzz1 zzz2
+//   level 3:  ppp = p pp      q = u1 pp       zz3 = z12 pp                          (x3 = rr - ppp - 2 q)
+//   level 4:  r (q - x3)      s1 ppp          zzz3 = z123 ppp                       (y3 = the difference)
+// The four lanes of a quad hold the SAME operands (the same coordinates, not merely the same point), take one product
+// of a level each -- one instruction stream, different operands, nothing diverges inside a quad -- and exchange the
+// results by quad-permute DPP moves (no LDS, no barrier).  An addition then costs 4 multiplications of wave time
+// instead of 14, a doubling (dbl_coop's three levels) 3 instead of 10 1/2.  Every lane of the quad returns the same
+// coordinates.  Branches (infinity, P = +-Q) are uniform inside a quad by construction.
+template <int I>
+__device__ __forceinline__ uint32_t quad_word(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, I * 0x55, 0xf, 0xf, false);   // quad_perm:[I,I,I,I]
+}
+template <int I>
+__device__ __forceinline__ u256 quad_get(const u256& v) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = quad_word<I>(v.v[i]);
+  return r;
+}
+template <int I>
+__device__ __forceinline__ fp2_t quad_get(const fp2_t& v) { return fp2_t{quad_get<I>(v.c0), quad_get<I>(v.c1)}; }
+template <class E>
+__device__ __forceinline__ E sel4(uint32_t role, const E& a, const E& b, const E& c, const E& d) {
+  return role == 0 ? a : (role == 1 ? b : (role == 2 ? c : d));
+}
+template <class C>
+__device__ __forceinline__ typename C::Acc dbl_quad(const typename C::Acc& p) {
+  using F = typename C::Field;
+  using E = typename C::E;
+  const uint32_t q = threadIdx.x & 3, role = q < 2 ? q : 2;   // lane 3 repeats lane 2's product
+  const E u = F::dbl(p.y);
+  const E l1 = F::sqr(role == 0 ? u : p.x);
+  const E v = quad_get<0>(l1), xx = quad_get<1>(l1);
+  const E m = F::add(F::dbl(xx), xx);
+  const E l2 = F::mul(sel3(role, u, p.x, m), role == 2 ? m : v);
+  const E w = quad_get<0>(l2), s = quad_get<1>(l2), mm = quad_get<2>(l2);
+  const E x3 = F::sub(mm, F::dbl(s));
+  const E l3 = F::mulsub(sel3(role, m, v, w), sel3(role, F::sub(s, x3), p.zz, p.zzz), role == 0 ? w : F::zero(), p.y);
+  return typename C::Acc{x3, quad_get<0>(l3), quad_get<1>(l3), quad_get<2>(l3)};   // infinity (all zero) maps to itself
+}
+template <class C>
+__device__ __forceinline__ typename C::Acc add_quad(const typename C::Acc& a, const typename C::Acc& b) {
+  using F = typename C::Field;
+  using E = typename C::E;
+  if (C::is_inf(b)) return a;
+  if (C::is_inf(a)) return b;
+  const uint32_t role = threadIdx.x & 3;
+  const E l1 = F::mul(sel4(role, a.x, b.x, a.y, b.y), sel4(role, b.zz, a.zz, b.zzz, a.zzz));
+  const E u1 = quad_get<0>(l1), u2 = quad_get<1>(l1), s1 = quad_get<2>(l1), s2 = quad_get<3>(l1);
+  const E p = F::sub(u2, u1), r = F::sub(s2, s1);
+  if (F::is_zero(p)) return F::is_zero(r) ? dbl_quad<C>(a) : C::acc_inf();
+  const E l2 = F::mul(sel4(role, p, r, a.zz, a.zzz), sel4(role, p, r, b.zz, b.zzz));
+  const E pp = quad_get<0>(l2), rr = quad_get<1>(l2), z12 = quad_get<2>(l2), z123 = quad_get<3>(l2);
+  const E l3 = F::mul(sel4(role, p, u1, z12, z12), pp);
+  const E ppp = quad_get<0>(l3), qq = quad_get<1>(l3), zz3 = quad_get<2>(l3);
+  const E x3 = F::sub(F::sub(rr, ppp), F::dbl(qq));
+  const E l4 = F::mul(sel4(role, r, s1, z123, z123), role == 0 ? F::sub(qq, x3) : ppp);
+  return typename C::Acc{x3, F::sub(quad_get<0>(l4), quad_get<1>(l4)), zz3, quad_get<2>(l4)};
+}
+// k * P for a small k that is uniform over the quad
+template <class C>
+__device__ __forceinline__ typename C::Acc mul_small_quad(const typename C::Acc& p, uint32_t k) {
+  typename C::Acc r = C::acc_inf();
+#pragma unroll 1
+  for (int b = k ? 31 - __clz(k) : -1; b >= 0; --b) {
+    r = dbl_quad<C>(r);
+    if ((k >> b) & 1) r = add_quad<C>(r, p);
+  }
+  return r;
+}
+// sum over the SLOTS quads of a workgroup (4 * SLOTS threads), returned on every thread
+template <class C, int SLOTS>
+__device__ __forceinline__ typename C::Acc block_sum_quad(const typename C::Acc& v, typename C::Acc* sh) {
+  const int slot = threadIdx.x >> 2;
+  __syncthreads();
+  if ((threadIdx.x & 3) == 0) sh[slot] = v;
+  __syncthreads();
+#pragma unroll 1
+  for (int stride = SLOTS / 2; stride > 0; stride >>= 1) {
+    if (slot < stride) {
+      const typename C::Acc a = add_quad<C>(sh[slot], sh[slot + stride]);
+      if ((threadIdx.x & 3) == 0) sh[slot] = a;
+    }
+    __syncthreads();
+  }
+  const typename C::Acc r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// stage 2 of the bucket reduction (msm_reduce2's algorithm and outputs) with a quad per slot: 4 * SLOTS threads
+template <class C, int SLOTS>
+__global__ void __launch_bounds__(4 * SLOTS, tail_waves<C>()) msm_reduce2_quad(const MsmBatch<C> B, uint32_t chunks_per_window,
+                                                                               uint32_t rc) {
+  tail_prio();
+  extern __shared__ __align__(16) unsigned char smem[];
+  typename C::Acc* sh = reinterpret_cast<typename C::Acc*>(smem);
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const uint32_t w = blockIdx.x, M = chunks_per_window;
+  const typename C::Acc* R = J.chunkR + (size_t)w * M;
+  const typename C::Acc* A = J.chunkA + (size_t)w * M;
+  const uint32_t slot = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const uint32_t per = (M + SLOTS - 1) / SLOTS;
+  const uint32_t lo = slot * per, hi = (lo + per < M) ? lo + per : M;
+  typename C::Acc sumA = C::acc_inf(), run = C::acc_inf(), wsum = C::acc_inf();
+  if (lo < M) {
+#pragma unroll 1
+    for (uint32_t m = hi; m-- > lo;) {
+      wsum = add_quad<C>(wsum, run);
+      run = add_quad<C>(run, R[m]);
+      sumA = add_quad<C>(sumA, A[m]);
+    }
+  }
+  if (q == 0) sh[slot] = run;
+  __syncthreads();
+  typename C::Acc incl = run;
+#pragma unroll 1
+  for (int d = 1; d < SLOTS; d <<= 1) {
+    typename C::Acc other = C::acc_inf();
+    const bool has = (int)slot + d < SLOTS;
+    if (has) other = sh[slot + d];
+    __syncthreads();
+    if (has) incl = add_quad<C>(incl, other);
+    if (q == 0) sh[slot] = incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) J.wsum[65 + w] = incl;
+  typename C::Acc v = (slot >= 1 && lo < M) ? mul_small_quad<C>(incl, per) : C::acc_inf();
+  v = add_quad<C>(v, wsum);
+  v = mul_small_quad<C>(v, rc);
+  v = add_quad<C>(v, sumA);
+  const typename C::Acc tot = block_sum_quad<C, SLOTS>(v, sh);
+  if (threadIdx.x == 0) J.wsum[w] = tot;
 }
 
 // ---- K7: fold windows + canonical affine ------------------------------------------------------------
@@ -949,6 +1091,73 @@ __global__ void __launch_bounds__(128, tail_waves<C>()) msm_fold_classes(const M
     C::add(xs, ysum);
     if (J.out_acc) *J.out_acc = xs;
     if (J.out_aff) *J.out_aff = C::to_affine(xs);
+  }
+}
+
+// msm_fold_classes with a quad per slice: threads 0..255 (role A) form  sum e_v T_v  and finish, threads 256..511
+// (role B) form  sum y_v.  The barriers are shared, so B's slice-local doublings run while A scales its suffixes.
+template <class C>
+__global__ void __launch_bounds__(512, tail_waves<C>()) msm_fold_classes_quad(const MsmBatch<C> B, uint32_t log2ks) {
+  tail_prio();
+  extern __shared__ __align__(16) unsigned char smem[];
+  typename C::Acc* shA = reinterpret_cast<typename C::Acc*>(smem);   // 64 + 64 accumulators
+  const MsmJob<C>& J = B.job[blockIdx.y];
+  const typename C::Acc* __restrict__ set_sum = J.wsum;
+  const typename C::Acc* __restrict__ set_tot = J.wsum + 65;
+  const bool roleB = threadIdx.x >= 256;
+  typename C::Acc* sh = shA + (roleB ? 64 : 0);
+  const int lane = (threadIdx.x & 255) >> 2, q = threadIdx.x & 3;   // "lane" = slice, as in msm_fold_classes
+  const int z = lane < 32 ? 0 : lane < 40 ? 1 : lane < 42 ? 2 : 3;
+  const int first = z == 0 ? 0 : z == 1 ? 32 : z == 2 ? 40 : 42, end = z == 0 ? 32 : z == 1 ? 40 : z == 2 ? 42 : 43;
+  const bool live = lane < (int)MSM_CLASS_SLICES;
+  // A: inclusive suffix scan of T inside each class
+  typename C::Acc val = (!roleB && live && z < 3) ? set_tot[lane] : C::acc_inf();
+  if (q == 0) sh[lane] = val;
+  __syncthreads();
+#pragma unroll 1
+  for (int d = 1; d < 32; d <<= 1) {
+    const bool has = !roleB && lane + d < end && z < 3;
+    typename C::Acc other = C::acc_inf();
+    if (has) other = sh[lane + d];
+    __syncthreads();
+    if (has) val = add_quad<C>(val, other);
+    if (q == 0) sh[lane] = val;
+    __syncthreads();
+  }
+  if (!roleB) {
+    if (lane == first || z == 3 || !live) val = C::acc_inf();   // sigma = 0 carries weight 0
+    const int nd = z == 1 ? 2 : z == 2 ? 4 : 0;
+#pragma unroll 1
+    for (int i = 0; i < nd; ++i) val = dbl_quad<C>(val);
+  } else {
+    val = live ? set_sum[lane] : C::acc_inf();
+    val = dbl_quad<C>(val);                                                  // 2 W
+    if (live && z < 3) val = add_quad<C>(val, C::neg(set_tot[lane]));        // - T
+    const int nd = z == 0 ? 0 : z == 1 ? 2 : z == 2 ? 4 : 5;                // 4^z; X: 2 W -> 64 W
+#pragma unroll 1
+    for (int i = 0; i < nd; ++i) val = dbl_quad<C>(val);
+  }
+  // both sums: the same tree on either half (block_sum_quad over 64 slots, indexed inside the role)
+  __syncthreads();
+  if (q == 0) sh[lane] = val;
+  __syncthreads();
+#pragma unroll 1
+  for (int stride = 32; stride > 0; stride >>= 1) {
+    if (lane < stride) {
+      const typename C::Acc a = add_quad<C>(sh[lane], sh[lane + stride]);
+      if (q == 0) sh[lane] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) {
+    typename C::Acc xs = shA[0];
+#pragma unroll 1
+    for (uint32_t i = 0; i < log2ks + 1; ++i) xs = dbl_quad<C>(xs);
+    xs = add_quad<C>(xs, shA[64]);
+    if (threadIdx.x == 0) {
+      if (J.out_acc) *J.out_acc = xs;
+      if (J.out_aff) *J.out_aff = C::to_affine(xs);
+    }
   }
 }
 

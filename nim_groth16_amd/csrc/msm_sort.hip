@@ -30,7 +30,7 @@ static int32_t msm_batch(g16_ctx* ctx, hipStream_t st, const g16_msm_run* runs, 
     o += (bytes + 255) & ~size_t(255);
     return r;
   };
-  const size_t nchunks = P.nbuckets / RED_CHUNK;
+  const size_t nchunks = P.nbuckets / msm_red_chunk(P);
   const size_t o_partial = take(((size_t)P.nbuckets + P.max_extra) * psz29), o_chunkR = take(nchunks * asz),
                o_chunkA = take(nchunks * asz), o_wsum = take((size_t)(2 * 64 + 2) * asz);
   MsmBatch<C> B;

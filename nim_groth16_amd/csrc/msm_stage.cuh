@@ -36,10 +36,11 @@ static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const MsmParams& P, con
 template <class C>
 static int32_t stage_reduce1(g16_ctx* ctx, hipStream_t st, const MsmParams& P, const void* batch, uint32_t ny) {
   const bool g2 = sizeof(typename C::Aff) == 128;
-  const size_t nchunks = P.nbuckets / RED_CHUNK;
+  const uint32_t rc = msm_red_chunk(P);
+  const size_t nchunks = P.nbuckets / rc;
   KLAUNCH_ON(ctx, st, g2 ? "msm_reduce1_g2" : "msm_reduce1_g1", msm_reduce1<C>,
              dim3((uint32_t)((nchunks + MSM_BLOCK - 1) / MSM_BLOCK), ny), MSM_BLOCK, 0, *(const MsmBatch<C>*)batch,
-             P.nbuckets);
+             P.nbuckets, rc);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;
 }
@@ -49,7 +50,8 @@ template <class C>
 static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams& P, bool narrow_tail, const void* batch,
                                   uint32_t ny) {
   const bool g2 = sizeof(typename C::Aff) == 128;
-  const size_t nchunks = P.nbuckets / RED_CHUNK;
+  const uint32_t rc = msm_red_chunk(P);
+  const size_t nchunks = P.nbuckets / rc;
   const MsmBatch<C>& B = *(const MsmBatch<C>*)batch;
   // reduction sets: the windows themselves, or <= 64 slices of the merged bucket set.  reduce2 is a latency chain
   // whose length grows with the chunks per thread, so the slices are as small as the 64 lanes of msm_fold_merged
@@ -64,7 +66,7 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams&
     uint32_t cps = nchunks < want ? (uint32_t)nchunks : want;
     while (nchunks / cps > 64) cps <<= 1;
     nsets = (uint32_t)(nchunks / cps);
-    for (uint32_t ks = cps * RED_CHUNK; ks > 1; ks >>= 1) ++log2ks;
+    for (uint32_t ks = cps * rc; ks > 1; ks >>= 1) ++log2ks;
   }
   // Workgroup width of reduce2.  The kernel is a latency chain (serial chunk sums -> Hillis-Steele suffix scan ->
   // tree), and every scan step costs one group addition on EVERY wave of the workgroup.  Wide workgroups (512 / 256
@@ -78,17 +80,35 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams&
   constexpr int R2N = R2B / 4;
   const uint32_t cps = (uint32_t)(nchunks / nsets);
   const char* nm = g2 ? "msm_reduce2_g2" : "msm_reduce2_g1";
-  switch (g16_env().r2_width >= 0 ? g16_env().r2_width : (narrow_tail ? 1 : 0)) {
+  // (4-bucket chunks: a small bucket set, where the chain is everything -- wide)
+  // Small bucket sets (4-bucket chunks: a shard's point sets, small MSMs): the quad-cooperative kernels (msm.cuh: an
+  // addition in 4 multiplications of wave time instead of 14; tools/ubench_quad.hip: 2.1-2.4 x per operation).  At the
+  // 352 k buckets of a 2^20 proof they shorten the single proof by 0.2 ms (10.79 -> 10.59) and cost 0.5 % proofs/s
+  // (four waves per slice instead of one: profiles/r04_ab_tail_quad.txt), so there the narrow kernels stay.
+  // G16_TAIL_QUAD = 1 / 0 forces them everywhere / nowhere.
+  const bool quad = g16_env().r2_width < 0 && (g16_env().tail_quad >= 0 ? g16_env().tail_quad != 0 : rc <= 4);
+  if (quad) {
+    constexpr bool is_g1 = sizeof(typename C::Aff) == 64;
+    if (is_g1 && cps >= 512)   // G2 at 512 threads would have to live in 256 registers
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2_quad<C, is_g1 ? 128 : 64>), dim3(nsets, ny), is_g1 ? 512 : 256,
+                 (is_g1 ? 128 : 64) * sizeof(typename C::Acc), B, cps, rc);
+    else
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2_quad<C, 64>), dim3(nsets, ny), 256, 64 * sizeof(typename C::Acc), B, cps, rc);
+  } else
+  switch (g16_env().r2_width >= 0 ? g16_env().r2_width : (narrow_tail && rc > 4 ? 1 : 0)) {
     case 0:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), dim3(nsets, ny), R2B, R2B * sizeof(typename C::Acc), B, cps);
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), dim3(nsets, ny), R2B, R2B * sizeof(typename C::Acc), B, cps, rc);
       break;
     case 2:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, 64>), dim3(nsets, ny), 64, 64 * sizeof(typename C::Acc), B, cps);
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, 64>), dim3(nsets, ny), 64, 64 * sizeof(typename C::Acc), B, cps, rc);
       break;
     default:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), dim3(nsets, ny), R2N, R2N * sizeof(typename C::Acc), B, cps);
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), dim3(nsets, ny), R2N, R2N * sizeof(typename C::Acc), B, cps, rc);
   }
-  if (P.tables && P.mtab == 2)
+  if (P.tables && P.mtab == 2 && quad)
+    KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_classes_quad<C>, dim3(1, ny), 512,
+               128 * sizeof(typename C::Acc), B, log2ks);
+  else if (P.tables && P.mtab == 2)
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_classes<C>, dim3(1, ny), 128, 0, B, log2ks);
   else if (P.tables)
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_merged<C>, dim3(1, ny), 128, 0, B, nsets, log2ks);

@@ -418,6 +418,7 @@ static int32_t launch_witness_sorts(g16_ctx* ctx, const g16_pkey* k, uint32_t fl
   return G16_OK;
 }
 // phase 2: accumulate + reduce A1, B1, B2, C1 against them
+constexpr size_t G2_FIRST_MAX = size_t(1) << 18;
 static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const ProveBufs& b, hipEvent_t after) {
   int32_t rc;
   const size_t nw = k->w_hi - k->w_lo;
@@ -442,7 +443,17 @@ static int32_t launch_witness_msms(g16_ctx* ctx, const g16_pkey* k, const ProveB
   if (k->liveA && la != 0) HIPCHK(ctx, hipStreamWaitEvent(L[la].stream, ctx->ev_b, 0));
   if (after)
     for (int i = 0; i < nlanes; ++i) HIPCHK(ctx, hipStreamWaitEvent(L[i].stream, after, 0));
-  if ((rc = g16_msm_batch(ctx, L[1].stream, 2, &runB2, 1, 1, nullptr))) return rc;
+  // Small witness ranges (the shards of a proof spread over GPUs): the four accumulations together do not fill the
+  // GPU, every kernel is a latency chain and B2's -- G2 additions, ~4 x the wave time of G1's -- is the longest: its
+  // accumulation goes first, next to C1's only (the H accumulation continues C1's bucket sums: the second longest
+  // chain); A1 and B1 then run under B2's reduce / fold tail.
+  const bool g2_first = g16_env().g2_first >= 0 ? g16_env().g2_first != 0 : nw <= G2_FIRST_MAX;
+  if ((rc = g16_msm_batch(ctx, L[1].stream, 2, &runB2, 1, 1, g2_first ? ctx->ev_g2 : nullptr))) return rc;
+  if (g2_first) {
+    HIPCHK(ctx, hipStreamWaitEvent(L[la].stream, ctx->ev_g2, 0));
+    HIPCHK(ctx, hipStreamWaitEvent(L[lb].stream, ctx->ev_g2, 0));
+    if (!chain || g16_env().g2_first == 2) HIPCHK(ctx, hipStreamWaitEvent(L[lc].stream, ctx->ev_g2, 0));
+  }
   if (batch) {
     if ((rc = g16_msm_batch(ctx, L[0].stream, 1, runs, 3, chain ? 2 : 3, chain ? ctx->ev_c : nullptr))) return rc;
   } else {

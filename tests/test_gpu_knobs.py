@@ -1,7 +1,7 @@
 """The code paths that only non-default settings reach, each in its own process (G16_* knobs are read once per process):
 small table windows (the partition sort with fewer than 8 low bits: bucket_place without the fused bookkeeping), the
 atomic histogram / scatter sort, wide and single-wave reduce2, compaction of (0,0) points forced on and off, the three
-NTT tile geometries, the alternative launch orders.  Every run proves a small circuit with skewed and infinity-laden
+NTT tile geometries, the alternative launch orders, the reduce chunk sizes and the one-lane / quad tails.  Every run proves a small circuit with skewed and infinity-laden
 inputs and compares proof, MSMs and NTTs with the oracle bit for bit."""
 import os
 import subprocess
@@ -79,6 +79,11 @@ KNOBS = [
     {"G16_TABLE_WINDOW": "17", "G16_MSM_SORT": "a"},           # class bucket set through the global-atomic sort
     {"G16_TABLE_WINDOW": "16", "G16_MSM_SEG": "8", "G16_G1_BATCH": "1"},   # class set + split buckets + batched tails
     {"G16_CHAIN_CH": "1", "G16_MSM_SEG": "8", "G16_INF_COMPACT": "0"},   # the chain across split buckets and own sorts
+    # small bucket sets default to 4-bucket reduce chunks, quad-cooperative reduce2 / fold and B2 first: the other side
+    {"G16_TAIL_QUAD": "0", "G16_RED_CHUNK": "16", "G16_G2_FIRST": "0"},
+    {"G16_TAIL_QUAD": "1", "G16_RED_CHUNK": "8", "G16_G2_FIRST": "2", "G16_TABLE_WINDOW": "16"},
+    {"G16_TAIL_QUAD": "1", "G16_RED_CHUNK": "2", "G16_MTAB": "1"},       # quad reduce2 in front of the one-lane merged fold
+    {"G16_TAIL_QUAD": "1", "G16_MSM_WINDOW": "16"},                     # 2048 chunks per window: the 128-slot G1 variant
 ]
 
 
