@@ -40,8 +40,8 @@ struct G16Env {
                                   // (bit-identical; measured: passes -5 %, fused last pass +18 %, proofs/s -1.6 %)
   int mtab = 2;                   // G16_MTAB=1: registered sets without the second multiplier table / class bucket set
   int chain_ch = 1;               // G16_CHAIN_CH=0: C1 and H1 as two MSMs instead of H1 continuing C1's bucket sums
-  int tail_quad = -1;             // G16_TAIL_QUAD = 0 | 1: reduce2 / fold with one lane / a cooperating quad per slot (msm.cuh;
-                                  // unset: quads for small bucket sets, msm_stage.cuh)
+  int tail_quad = 1;              // G16_TAIL_QUAD=0: reduce2 / fold with one lane per slot instead of a cooperating quad (msm.cuh,
+                                  // msm_stage.cuh)
   int red_chunk = 0;              // G16_RED_CHUNK = 2 | 4 | 8 | 16: buckets per thread of msm_reduce1 (unset: msm_red_chunk)
   int g2_first = -1;              // G16_G2_FIRST = 0 | 1 | 2: A1 and B1 (2: C1 too) accumulate after B2 (unset: 1 for small shards,
                                   // prover.hip)

@@ -81,12 +81,12 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams&
   const uint32_t cps = (uint32_t)(nchunks / nsets);
   const char* nm = g2 ? "msm_reduce2_g2" : "msm_reduce2_g1";
   // (4-bucket chunks: a small bucket set, where the chain is everything -- wide)
-  // Small bucket sets (4-bucket chunks: a shard's point sets, small MSMs): the quad-cooperative kernels (msm.cuh: an
-  // addition in 4 multiplications of wave time instead of 14; tools/ubench_quad.hip: 2.1-2.4 x per operation).  At the
-  // 352 k buckets of a 2^20 proof they shorten the single proof by 0.2 ms (10.79 -> 10.59) and cost 0.5 % proofs/s
-  // (four waves per slice instead of one: profiles/r04_ab_tail_quad.txt), so there the narrow kernels stay.
-  // G16_TAIL_QUAD = 1 / 0 forces them everywhere / nowhere.
-  const bool quad = g16_env().r2_width < 0 && (g16_env().tail_quad >= 0 ? g16_env().tail_quad != 0 : rc <= 4);
+  // Default: the quad-cooperative kernels (msm.cuh: an addition in 4 multiplications of wave time instead of 14;
+  // tools/ubench_quad.hip: 2.1-2.4 x per operation).  Shards: 2.71-2.94 -> 2.61-2.82 ms per rank at G = 8; 2^20 proofs:
+  // single-proof latency 10.79 -> 10.59 and 10.84 -> 10.54 ms in two sessions, proofs/s 121.57 -> 120.91 and 119.23 ->
+  // 120.63, i.e. inside the noise (profiles/r04_ab_tail_quad.txt, r04_ab_g2first_2p20.txt).  G16_TAIL_QUAD=0 or any
+  // G16_R2_WIDTH selects the one-lane-per-slot kernels of rounds 1-3 (narrow inside proofs, wide stand-alone).
+  const bool quad = g16_env().r2_width < 0 && g16_env().tail_quad != 0;
   if (quad) {
     constexpr bool is_g1 = sizeof(typename C::Aff) == 64;
     if (is_g1 && cps >= 512)   // G2 at 512 threads would have to live in 256 registers
