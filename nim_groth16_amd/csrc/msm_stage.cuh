@@ -46,6 +46,7 @@ static int32_t stage_reduce1(g16_ctx* ctx, hipStream_t st, const MsmParams& P, c
 }
 
 // MsmJob::wsum: room for 2 * 64 + 2 accumulators
+// narrow_tail: the caller overlaps this tail with other work (only read by the one-lane kernels, below)
 template <class C>
 static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams& P, bool narrow_tail, const void* batch,
                                   uint32_t ny) {
@@ -68,42 +69,42 @@ static int32_t stage_reduce2_fold(g16_ctx* ctx, hipStream_t st, const MsmParams&
     nsets = (uint32_t)(nchunks / cps);
     for (uint32_t ks = cps * rc; ks > 1; ks >>= 1) ++log2ks;
   }
-  // Workgroup width of reduce2.  The kernel is a latency chain (serial chunk sums -> Hillis-Steele suffix scan ->
-  // tree), and every scan step costs one group addition on EVERY wave of the workgroup.  Wide workgroups (512 / 256
-  // threads: one chunk per thread) have the shortest chain; narrow ones (128 / 64 threads: four chunks per thread,
-  // work-efficient serial sums, a 7- / 6-step scan) issue ~2.5x fewer wave-instructions for a ~20 % longer chain.
-  // A proof's throughput is bound by instruction issue over ALL its kernels (same-box A/B, profiles/r03_ab_knobs.txt:
-  // 111.6 -> 114.7 proofs/s, single-proof latency 11.67 -> 11.85 ms), so the prover's lanes use narrow; a stand-alone
-  // MSM (g16_msm_*: the msmMultiThreaded drop-in, nothing to overlap with) keeps wide: a 2^20 G2 MSM is 5.25 ms wide,
-  // 5.7 ms narrow.  G16_R2_WIDTH = 0 / 1 / 2 forces wide / narrow / a single wave per slice everywhere.
-  constexpr int R2B = sizeof(typename C::Aff) == 64 ? 512 : 256;
+  // reduce2 is a latency chain (serial chunk sums -> Hillis-Steele suffix scan -> tree).
+  // Default: the quad-cooperative kernels (msm.cuh: an addition in 4 multiplications of wave time instead of 14;
+  // tools/ubench_quad.hip: 2.1-2.4 x per operation), 64 slots per slice (128 for G1 slices of >= 512 chunks; G2 at 512
+  // threads would have to live in 256 registers).  Shards: 2.71-2.94 -> 2.61-2.82 ms per rank at G = 8; stand-alone 2^20
+  // MSM 2.18 -> 2.00 ms (G1), 5.21 -> 4.87 (G2); 2^20 proofs: single-proof latency 10.79 -> 10.59 and 10.84 -> 10.54 ms in
+  // two sessions, proofs/s 121.57 -> 120.91 and 119.23 -> 120.63, i.e. inside the noise (profiles/r04_ab_tail_quad.txt,
+  // r04_ab_g2first_2p20.txt, r04_perf_reg_quad.txt).
+  // G16_TAIL_QUAD=0 or any G16_R2_WIDTH selects the one-lane-per-slot kernels of rounds 1-3.  There every scan step costs
+  // one group addition on EVERY wave of the workgroup: wide workgroups (512 / 256 threads: one chunk per thread) have the
+  // shortest chain; narrow ones (128 / 64 threads: four chunks per thread, work-efficient serial sums, a 7- / 6-step
+  // scan) issue ~2.5x fewer wave-instructions for a ~20 % longer chain and were the choice inside proofs (same-box A/B,
+  // profiles/r03_ab_knobs.txt: 111.6 -> 114.7 proofs/s, 11.67 -> 11.85 ms), wide for stand-alone MSMs and for 4-bucket
+  // chunks.  G16_R2_WIDTH = 0 / 1 / 2 forces wide / narrow / a single wave per slice.
+  constexpr bool is_g1 = sizeof(typename C::Aff) == 64;
+  constexpr int R2B = is_g1 ? 512 : 256;
   constexpr int R2N = R2B / 4;
   const uint32_t cps = (uint32_t)(nchunks / nsets);
   const char* nm = g2 ? "msm_reduce2_g2" : "msm_reduce2_g1";
-  // (4-bucket chunks: a small bucket set, where the chain is everything -- wide)
-  // Default: the quad-cooperative kernels (msm.cuh: an addition in 4 multiplications of wave time instead of 14;
-  // tools/ubench_quad.hip: 2.1-2.4 x per operation).  Shards: 2.71-2.94 -> 2.61-2.82 ms per rank at G = 8; 2^20 proofs:
-  // single-proof latency 10.79 -> 10.59 and 10.84 -> 10.54 ms in two sessions, proofs/s 121.57 -> 120.91 and 119.23 ->
-  // 120.63, i.e. inside the noise (profiles/r04_ab_tail_quad.txt, r04_ab_g2first_2p20.txt).  G16_TAIL_QUAD=0 or any
-  // G16_R2_WIDTH selects the one-lane-per-slot kernels of rounds 1-3 (narrow inside proofs, wide stand-alone).
   const bool quad = g16_env().r2_width < 0 && g16_env().tail_quad != 0;
   if (quad) {
-    constexpr bool is_g1 = sizeof(typename C::Aff) == 64;
-    if (is_g1 && cps >= 512)   // G2 at 512 threads would have to live in 256 registers
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2_quad<C, is_g1 ? 128 : 64>), dim3(nsets, ny), is_g1 ? 512 : 256,
-                 (is_g1 ? 128 : 64) * sizeof(typename C::Acc), B, cps, rc);
+    if (is_g1 && cps >= 512)
+      KLAUNCH_ON(ctx, st, nm, (msm_reduce2_quad<C, is_g1 ? 128 : 64>), dim3(nsets, ny), 512, 128 * sizeof(typename C::Acc), B,
+                 cps, rc);
     else
       KLAUNCH_ON(ctx, st, nm, (msm_reduce2_quad<C, 64>), dim3(nsets, ny), 256, 64 * sizeof(typename C::Acc), B, cps, rc);
-  } else
-  switch (g16_env().r2_width >= 0 ? g16_env().r2_width : (narrow_tail && rc > 4 ? 1 : 0)) {
-    case 0:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), dim3(nsets, ny), R2B, R2B * sizeof(typename C::Acc), B, cps, rc);
-      break;
-    case 2:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, 64>), dim3(nsets, ny), 64, 64 * sizeof(typename C::Acc), B, cps, rc);
-      break;
-    default:
-      KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), dim3(nsets, ny), R2N, R2N * sizeof(typename C::Acc), B, cps, rc);
+  } else {
+    switch (g16_env().r2_width >= 0 ? g16_env().r2_width : (narrow_tail && rc > 4 ? 1 : 0)) {
+      case 0:
+        KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2B>), dim3(nsets, ny), R2B, R2B * sizeof(typename C::Acc), B, cps, rc);
+        break;
+      case 2:
+        KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, 64>), dim3(nsets, ny), 64, 64 * sizeof(typename C::Acc), B, cps, rc);
+        break;
+      default:
+        KLAUNCH_ON(ctx, st, nm, (msm_reduce2<C, R2N>), dim3(nsets, ny), R2N, R2N * sizeof(typename C::Acc), B, cps, rc);
+    }
   }
   if (P.tables && P.mtab == 2 && quad)
     KLAUNCH_ON(ctx, st, g2 ? "msm_fold_g2" : "msm_fold_g1", msm_fold_classes_quad<C>, dim3(1, ny), 512,
