@@ -51,10 +51,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=288,
                     help="timed proofs (default 288: a ~2.5-s timed region at 2^20; round 2's 96 steps = 0.9 s were within box noise)")
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=0,
                     help="the timed region (exactly --steps proofs, barriers on both sides) is run this many times; "
-                         "`value` / `ms_per_step` are the median run, every run is listed in `value_runs` (a 20-step "
-                         "region is 0.17 s: one such run is the noisiest number this file can print)")
+                         "`value` / `ms_per_step` are the median run, every run is listed in `value_runs`.  Default: 5, "
+                         "or 11 for regions of fewer than 96 steps (a 20-step region is 0.17 s: single ones scatter by "
+                         "+-4 %, medians of five by +-1.7 % on the noisiest box, profiles/r04_bench_repeat.txt)")
     ap.add_argument("--log2n", type=int, default=20, help="domain size 2^log2n (constraints m = 2^log2n - 2)")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,7 +315,8 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     ctx.profile(2 if rank == 0 else 0)
     ctx.profile_reset()
     runs = []
-    for _ in range(max(1, args.repeats)):
+    repeats = args.repeats if args.repeats > 0 else (5 if args.steps >= 96 else 11)
+    for _ in range(repeats):
         barrier()
         t0 = time.perf_counter()
         run(args.steps, hbm=args.witness == "hbm")

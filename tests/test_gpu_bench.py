@@ -41,7 +41,8 @@ def test_bench_single_gpu_small_domain_contract_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     # round 4: the timed region is repeated, `value` is the median run; the share of a step that is bucket accumulation
     # and the gather roofline are in the line
-    assert len(d["value_runs"]) == 5 and sorted(d["value_runs"])[2] == d["value"] and "median" in d["value_is"]
+    # (11 regions when a region is shorter than 96 steps, else 5)
+    assert len(d["value_runs"]) == 11 and sorted(d["value_runs"])[5] == d["value"] and "median" in d["value_is"]
     assert d["accum_ms_per_proof"] > 0 and 0 < d["overlap_efficiency"] < 1.5
     g = d["roofline_gather"]
     for k in ("kernel", "hbm_bytes_per_launch_by_counters", "avg_launch_ms", "ceiling_gb_s", "ceiling_from", "frac"):
