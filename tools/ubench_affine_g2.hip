@@ -1,5 +1,5 @@
 // Micro-benchmark: batched-AFFINE G2 additions with real memory traffic, against the mixed XYZZ addition of
-// msm_accum<G2>.
+// msm_accum<G2> (DESIGN §5 "Not pursued").
 //
 // Every lane adds K independent pairs of affine G2 points (gathered at random from a 1.7-GB table, like the bucket
 // entries of a 2^20 MSM) sharing ONE inversion (Montgomery's trick):

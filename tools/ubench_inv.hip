@@ -1,4 +1,4 @@
-// Micro-benchmark for the batched-affine question: what does ONE field
+// Micro-benchmark for the batched-affine question (DESIGN §5 "Not pursued"): what does ONE field
 // inversion cost a wave, in units of the 9x29 multiplication the accumulate kernels are built from?
 // Every lane inverts its own (different) value -- data-dependent, so the 64 lanes of a wave diverge and the wave pays
 // for the slowest path of every step -- with (a) the binary extended Euclid of rounds 1-2 (Fp::inv_eea) and (b) the
