@@ -232,6 +232,17 @@ int32_t g16_prove_partials_end(g16_ctx* ctx, const g16_pkey* key, const void* d_
                                const void* d_c1_slice, uint32_t flags, void* out_partials);
 /* buildABC alone (prover.nim:56-73): out_abc = Az | Bz | Cz, 3 * domainSize Fr (Montgomery), host memory */
 int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* key, const void* witness, uint32_t flags, void* out_abc);
+/* shape of the key's A / B matrices as buildABC sees them (ZKey.coeffs, zkey_types.nim:48-59; files/zkey.nim:169-192):
+ * out[0] = ncoeffs; out[1] = distinct coefficient values if the key runs on a value dictionary (entries are then
+ * 8 bytes: column + value index), else 0 (36 bytes: column + value); out[2 + g], g = 0..6 = rows served by groups of
+ * 2^g lanes (a row's longer entry list L: g = 0 for L <= 4, else 4 * 2^(g-1) < L <= 4 * 2^g; g = 6 takes all longer) */
+int32_t g16_pkey_abc_info(const g16_pkey* key, size_t out[9]);
+/* y = M x over Fr (Montgomery in and out) for a sparse M given as nnz triplets (row[i], col[i], val[i] = 32 bytes);
+ * entries of one row add up.  The same row-balanced kernel as buildABC.  Replaces the sparse column dot products of
+ * the fake setup -- `for each coefficient: taus[wire] += value * L_row(tau)` (fake_setup.nim:159-187, 254-256): pass
+ * row = wire, col = constraint, x = the Lagrange values.  Host pointers; x: ncols elements, y: nrows elements. */
+int32_t g16_spmv_fr(g16_ctx* ctx, const uint32_t* row, const uint32_t* col, const void* val, size_t nnz, const void* x,
+                    size_t ncols, size_t nrows, void* y);
 
 /* ---- verifier ------------------------------------------------------------------------
  * Replaces verifyProof (groth16/verifier.nim:31-52), extractVKey / VKey (groth16/zkey_types.nim:62-73) and the

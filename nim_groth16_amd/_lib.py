@@ -20,7 +20,7 @@ SYMBOLS = [
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_inf_count", "g16_points_info", "g16_msm_points",
     "g16_points_check_g1", "g16_points_check_g2", "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
-    "g16_pkey_destroy", "g16_pkey_inf_counts", "g16_prove", "g16_build_abc", "g16_prove_partials", "g16_prove_combine",
+    "g16_pkey_destroy", "g16_pkey_inf_counts", "g16_prove", "g16_build_abc", "g16_pkey_abc_info", "g16_spmv_fr", "g16_prove_partials", "g16_prove_combine",
     "g16_prove_partials_begin", "g16_prove_partials_end",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report", "g16_profile_clock",
     "g16_vkey_create", "g16_vkey_destroy", "g16_verify", "g16_pairing",
@@ -142,6 +142,8 @@ def load_library():
     lib.g16_pkey_destroy.restype = None
     lib.g16_prove.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     lib.g16_build_abc.argtypes = [vp, vp, vp, u32, vp]
+    lib.g16_pkey_abc_info.argtypes = [vp, ctypes.POINTER(sz)]
+    lib.g16_spmv_fr.argtypes = [vp, vp, vp, vp, sz, vp, sz, sz, vp]
     lib.g16_prove_partials.argtypes = [vp, vp, vp, u32, vp]
     lib.g16_prove_combine.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp]
     lib.g16_prove_partials_begin.argtypes = [vp, vp, vp, u32, u32, vp]
@@ -269,6 +271,22 @@ class Context:
         fn = self._lib.g16_fixed_base_g1 if group == 1 else self._lib.g16_fixed_base_g2
         self._check(fn(self._h, _buf(scalars) if n else None, SCALARS_MONT if mont else 0, n, out))
         return out.raw[: n * psz]
+
+    def spmv(self, row, col, val, x: bytes, nrows: int) -> bytes:
+        """y = M x over Fr (Montgomery): M as triplets -- row, col: uint32 numpy arrays; val: nnz x 32 bytes (numpy
+        uint8 array or bytes); x: ncols Fr.  The sparse column dot products of fake_setup.nim:159-187 on the GPU."""
+        import numpy as np
+        row = np.ascontiguousarray(row, dtype=np.uint32)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        nnz = len(row)
+        if not isinstance(val, (bytes, bytearray)):
+            val = np.ascontiguousarray(val, dtype=np.uint8)
+        assert len(col) == nnz and (len(val) if isinstance(val, (bytes, bytearray)) else val.size) == 32 * nnz
+        out = ctypes.create_string_buffer(max(1, 32 * nrows))
+        self._check(self._lib.g16_spmv_fr(self._h, _buf(row) if nnz else None, _buf(col) if nnz else None,
+                                          _buf(val) if nnz else None, nnz, _buf(x) if len(x) else None, len(x) // 32,
+                                          nrows, out))
+        return out.raw[: 32 * nrows]
 
     def quotient(self, Az, Bz, Cz, log2n: int, flavour: int, out=None, device: bool = False):
         if device:
@@ -408,6 +426,13 @@ class ProvingKey:
         v = list(out)
         return {"A1": v[0], "B1": v[1], "B2": v[2], "C1": v[3], "H1": v[4], "B1_and_B2": v[5],
                 "compact_A": bool(v[6]), "compact_B": bool(v[7])}
+
+    def abc_info(self) -> dict:
+        """shape of the A / B matrices as buildABC runs them (g16_pkey_abc_info)"""
+        out = (ctypes.c_size_t * 9)()
+        self.ctx._check(self.ctx._lib.g16_pkey_abc_info(self._h, out))
+        v = list(out)
+        return {"ncoeffs": v[0], "dict_values": v[1], "rows_per_group_size": {1 << g: v[2 + g] for g in range(7)}}
 
     def build_abc(self, witness: bytes, mont: bool = True, ctx=None):
         c = ctx or self.ctx

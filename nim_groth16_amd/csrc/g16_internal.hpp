@@ -43,6 +43,8 @@ struct G16Env {
   int tail_quad = 1;              // G16_TAIL_QUAD=0: reduce2 / fold with one lane per slot instead of a cooperating quad (msm.cuh,
                                   // msm_stage.cuh)
   int red_chunk = 0;              // G16_RED_CHUNK = 2 | 4 | 8 | 16: buckets per thread of msm_reduce1 (unset: msm_red_chunk)
+  int abc_dict = 1;               // G16_ABC_DICT=0: buildABC reads a 32-byte value per entry even when the key's coefficients
+                                  // come from a small set (spmv.hip: value dictionary)
   int g2_first = -1;              // G16_G2_FIRST = 0 | 1 | 2: A1 and B1 (2: C1 too) accumulate after B2 (unset: 1 for small shards,
                                   // prover.hip)
 };
@@ -294,6 +296,14 @@ int32_t g16_bitmap_or_device(g16_ctx* ctx, uint32_t* d_out, const uint32_t* d_a,
                              uint32_t* d_n_dead);
 int32_t g16_sum_partials_device_g1(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
 int32_t g16_sum_partials_device_g2(g16_ctx* ctx, const void* d_parts, uint32_t count, void* d_out_aff);
+// row-binned sparse matrices over Fr (spmv.hip): nmat = 2 -> the A and B matrices of a key, apply = buildABC
+struct g16_spmat;
+int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
+                         size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
+                         size_t val_stride, g16_spmat** out);
+void g16_spmat_destroy(g16_spmat* m);
+void g16_spmat_info(const g16_spmat* m, size_t out[8]);   // dictionary size (0: plain values), rows per bin
+int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out);
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse);
 // computeSnarkjsScalarCoeffs (flavour 1, prover.nim:158-181) / computeQuotientPointwise (flavour 0, :118-148)
 // d_a, d_b, d_c, d_out: n elements each (device); inputs are not modified

@@ -1,6 +1,6 @@
 // Proving-key residency and the per-proof launch sequence: the GPU counterpart of
 // generateProofWithMask (reference groth16/prover.nim:215-304).
-//   buildABC                      prover.nim:56-73     -> abc_spmv kernel (CSR built once per key)
+//   buildABC                      prover.nim:56-73     -> spmv_binned kernel (spmv.hip; rows binned once per key)
 //   computeSnarkjsScalarCoeffs /  prover.nim:158-181   -> g16_quotient_device (ntt.hip)
 //   computeQuotientPointwise      prover.nim:118-148
 //   5 x msmMultiThreaded          prover.nim:282-302   -> msm_device on the registered point tables
@@ -26,10 +26,8 @@ struct g16_pkey {
   size_t w_lo = 0, w_hi = 0;   // A1 / B1 / B2 / C1 : range of wires (C1 is stored wire-aligned, see below)
   size_t h_lo = 0, h_hi = 0;   // H1                : range of domain indices
   g16_points *A1 = nullptr, *B1 = nullptr, *B2 = nullptr, *C1 = nullptr, *H1 = nullptr;
-  // CSR of the A and B matrices (zkey section 4 / ZKey.coeffs, zkey_types.nim:48-59)
-  uint32_t* d_rowptr = nullptr;  // [2][n+1]
-  uint32_t* d_col = nullptr;
-  u256* d_val = nullptr;
+  // the A and B matrices (zkey section 4 / ZKey.coeffs, zkey_types.nim:48-59), row-binned for buildABC (spmv.hip)
+  g16_spmat* abc = nullptr;
   size_t ncoeffs = 0;
   g1_aff alpha1, beta1, delta1;
   g2_aff beta2, delta2;
@@ -42,31 +40,6 @@ struct g16_pkey {
   uint32_t* liveB = nullptr;      // owned (the union), or nullptr
   size_t deadB = 0;               // wires whose B1 AND B2 points are both (0,0)
 };
-
-// ---- buildABC ---------------------------------------------------------------------------------------
-// one thread per row: Az[r] = sum A[r][c] z[c], Bz likewise, Cz = Az * Bz   (prover.nim:56-73)
-static __global__ void __launch_bounds__(256) abc_spmv(const uint32_t* __restrict__ rowptr,
-                                                       const uint32_t* __restrict__ col,
-                                                       const u256* __restrict__ val, const u256* __restrict__ wit,
-                                                       uint32_t wit_mont, uint32_t n, u256* __restrict__ abc) {
-  uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
-  u256 acc[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    u256 a = Fr::zero();
-    const uint32_t* rp = rowptr + (size_t)m * (n + 1);
-    for (uint32_t e = rp[r]; e < rp[r + 1]; ++e) {
-      u256 w = wit[col[e]];
-      if (!wit_mont) w = Fr::to_mont(w);
-      a = Fr::add(a, Fr::mul(val[e], w));
-    }
-    acc[m] = a;
-  }
-  abc[r] = acc[0];
-  abc[(size_t)n + r] = acc[1];
-  abc[2 * (size_t)n + r] = Fr::mul(acc[0], acc[1]);
-}
 
 // ---- host-side O(1) curve helpers (the reference does these on the host too: curves.nim:136-214) ------
 // 64-bit-limb host field (host_ff64.hpp) under the same curve templates; 4-bit fixed windows.
@@ -146,9 +119,7 @@ extern "C" void g16_pkey_destroy(g16_pkey* k) {
   // like g16_points_release: wait for the device, not for a context (the creating one may be gone already)
   (void)hipSetDevice(k->device);
   (void)hipDeviceSynchronize();
-  if (k->d_rowptr) (void)hipFree(k->d_rowptr);
-  if (k->d_col) (void)hipFree(k->d_col);
-  if (k->d_val) (void)hipFree(k->d_val);
+  g16_spmat_destroy(k->abc);
   if (k->liveB) (void)hipFree(k->liveB);
   delete k;
 }
@@ -162,6 +133,13 @@ extern "C" int32_t g16_pkey_inf_counts(const g16_pkey* k, size_t out[8]) {
   const size_t pad = pub_end > k->w_lo ? pub_end - k->w_lo : 0;
   out[0] = k->A1->n_inf, out[1] = k->B1->n_inf, out[2] = k->B2->n_inf, out[3] = k->C1->n_inf - pad, out[4] = k->H1->n_inf;
   out[5] = k->deadB, out[6] = k->liveA ? 1 : 0, out[7] = k->liveB ? 1 : 0;
+  return G16_OK;
+}
+
+extern "C" int32_t g16_pkey_abc_info(const g16_pkey* k, size_t out[9]) {
+  if (!k || !out) return G16_EINVAL;
+  out[0] = k->ncoeffs;
+  g16_spmat_info(k->abc, out + 1);
   return G16_OK;
 }
 
@@ -245,47 +223,21 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
       }
     }
   }
-  // CSR by counting sort on (matrix, row): A entries first, then B (sum order is irrelevant mod r)
+  // the A and B entries in row order, rows binned by length (sum order is irrelevant mod r)
   const g16_coeff* cf = (const g16_coeff*)d->coeffs;
-  std::vector<uint32_t> rowptr(2 * (n + 1), 0);
-  {
-    std::vector<uint32_t> cnt(2 * (n + 1), 0);
-    for (size_t e = 0; e < d->ncoeffs; ++e) {
-      if (cf[e].matrix > 1 || cf[e].row >= n || cf[e].col >= d->nvars) {
-        // MatrixC entries make the reference's buildABC raise (prover.nim:67)
-        ctx->err = "coefficient entry out of range (matrix must be 0=A or 1=B)";
-        g16_pkey_destroy(k);
-        return G16_EINVAL;
-      }
-      cnt[cf[e].matrix * (n + 1) + cf[e].row]++;
+  std::vector<uint32_t> vrow(d->ncoeffs ? d->ncoeffs : 1);
+  for (size_t e = 0; e < d->ncoeffs; ++e) {
+    if (cf[e].matrix > 1 || cf[e].row >= n || cf[e].col >= d->nvars) {
+      // MatrixC entries make the reference's buildABC raise (prover.nim:67)
+      ctx->err = "coefficient entry out of range (matrix must be 0=A or 1=B)";
+      g16_pkey_destroy(k);
+      return G16_EINVAL;
     }
-    uint32_t pos = 0;
-    for (int m = 0; m < 2; ++m)
-      for (size_t r = 0; r <= n; ++r) {
-        rowptr[m * (n + 1) + r] = pos;
-        if (r < n) pos += cnt[m * (n + 1) + r];
-      }
-  }
-  std::vector<uint32_t> cols(d->ncoeffs ? d->ncoeffs : 1);
-  std::vector<u256> vals(d->ncoeffs ? d->ncoeffs : 1);
-  {
-    std::vector<uint32_t> cur(rowptr);
-    for (size_t e = 0; e < d->ncoeffs; ++e) {
-      uint32_t& p = cur[cf[e].matrix * (n + 1) + cf[e].row];
-      cols[p] = cf[e].col;
-      memcpy(&vals[p], cf[e].value, 32);
-      ++p;
-    }
+    vrow[e] = 2 * cf[e].row + cf[e].matrix;
   }
   k->ncoeffs = d->ncoeffs;
-  auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t {
-    if (hipMalloc(dst, bytes ? bytes : 4) != hipSuccess) return G16_ENOMEM;
-    if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return G16_EHIP;
-    return G16_OK;
-  };
-  TRY(up((void**)&k->d_rowptr, rowptr.data(), rowptr.size() * 4));
-  TRY(up((void**)&k->d_col, cols.data(), d->ncoeffs * 4));
-  TRY(up((void**)&k->d_val, vals.data(), d->ncoeffs * 32));
+  TRY(g16_spmat_create(ctx, 2, (uint32_t)n, d->ncoeffs, vrow.data(), 4, d->ncoeffs ? &cf[0].col : nullptr,
+                       sizeof(g16_coeff), d->ncoeffs ? cf[0].value : nullptr, sizeof(g16_coeff), &k->abc));
 #undef TRY
   *out = k;
   return G16_OK;
@@ -293,11 +245,7 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
 
 // Az | Bz | Cz for a witness (device buffers); exposed for tests of the buildABC kernel
 static int32_t build_abc_device(g16_ctx* ctx, const g16_pkey* k, const u256* d_wit, uint32_t wit_mont, u256* d_abc) {
-  const uint32_t n = 1u << k->log2n;
-  KLAUNCH(ctx, "abc_spmv", abc_spmv, (n + 255) / 256, 256, 0, k->d_rowptr, k->d_col, k->d_val, d_wit, wit_mont, n,
-          d_abc);
-  HIPCHK(ctx, hipGetLastError());
-  return G16_OK;
+  return g16_spmat_apply(ctx, k->abc, d_wit, wit_mont, d_abc);
 }
 
 extern "C" int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, void* out_abc) {

@@ -1,0 +1,324 @@
+// Sparse matrix x vector over Fr, row-balanced: the GPU counterpart of buildABC (reference groth16/prover.nim:56-73)
+// and of the sparse column dot products of the fake setup (fake_setup.nim:159-187, 254-256).
+//
+// The reference walks ZKey.coeffs (files/zkey.nim:169-192: one 44-byte entry per non-zero of A and B) sequentially
+// and adds value * witness[col] into Az[row] / Bz[row].  A thread per row (rounds 1-4) is fine for rows of one or two
+// terms; a circom circuit (Poseidon, Merkle paths: config 5 of BASELINE.json) has rows of 3-30+ terms next to rows of
+// one, and a wave is then as slow as its longest row while its lanes read 32-byte values at strides of a kilobyte.
+//
+// Layout, built once per key (the matrices are per-circuit constants like the point sets):
+//   * entries in row order, the A entries of row r followed by its B entries: ptr[2 r], ptr[2 r + 1], ptr[2 r + 2]
+//     (one matrix: ptr[r], ptr[r + 1]); col / val arrays parallel to it
+//   * rows sorted into seven BINS by L = the longer of their (up to two) entry lists: bin g serves a row with a GROUP
+//     of 2^g lanes, 4 * 2^(g-1) < L <= 4 * 2^g (bin 0: L <= 4, incl. the empty rows of the padded domain; bin 6: all
+//     longer rows, looping).  Lane j of a group takes entries j, j + G, j + 2G, j + 3G: every load instruction of a
+//     group reads G consecutive entries, and all lanes of a wave have the same trip count.
+//   * a lane's (up to) four products are ONE Montgomery dot product (Fr::mul4: 4 x 64 multiply-adds + one 64-mad
+//     reduction instead of four); the group then adds its lanes' sums with log2 G cross-lane steps (ds_bpermute, no
+//     LDS memory), lane 0 forms Cz = Az * Bz (prover.nim:69-72) and writes the row.
+//   * a standard-form witness (raw .wtns values) is multiplied as it is -- (v R) w / R = v w -- and the row sum is
+//     brought to Montgomery form once per row, not once per entry.
+//   * value DICTIONARY: circuit coefficients come from a small set (+-1, MDS entries, round constants); when a key's
+//     non-zeros hold <= 65536 distinct values the entry stream is (col, value index) = 8 bytes instead of 36 and the
+//     value table stays in L2.
+#include <algorithm>
+#include <new>
+#include <unordered_map>
+
+#include "g16_internal.hpp"
+#include "ff.cuh"
+
+using namespace g16;
+
+namespace {
+
+constexpr int NBINS = 7;
+constexpr uint32_t BLOCK = 256;
+
+struct SpmvBins {
+  uint32_t row_off[NBINS + 1];   // bin g: rows[row_off[g] .. row_off[g + 1])
+  uint32_t blk_off[NBINS + 1];   // ... served by workgroups blk_off[g] .. blk_off[g + 1), 256 >> g rows each
+};
+
+__device__ __forceinline__ u256 shfl_xor_u256(const u256& a, int off) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], off, 64);
+  return r;
+}
+
+// sum over the entries [s, e) this lane owns (lane, lane + G, ...) of val * x[col]
+template <bool DICT>
+__device__ __forceinline__ u256 lane_dot(uint32_t s, uint32_t e, uint32_t lane, uint32_t g,
+                                         const uint32_t* __restrict__ col, const u256* __restrict__ val,
+                                         const uint32_t* __restrict__ vidx, const u256* __restrict__ x) {
+  const uint32_t G = 1u << g;
+  u256 a = Fr::zero();
+  for (uint32_t i = s + lane; i < e; i += 4 * G) {
+    const uint32_t k = (e - i + G - 1) >> g;   // entries of this trip: >= 1
+    u256 v[4], w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if ((uint32_t)j < k) {
+        const uint32_t idx = i + j * G;
+        v[j] = DICT ? val[vidx[idx]] : val[idx];
+        w[j] = x[col[idx]];
+      } else {
+        v[j] = Fr::zero();
+        w[j] = Fr::zero();
+      }
+    }
+    u256 t;
+    if (k == 1) t = Fr::mul(v[0], w[0]);
+    else if (k == 2) t = Fr::mul2(v[0], w[0], v[1], w[1]);
+    else t = Fr::mul4(v[0], w[0], v[1], w[1], v[2], w[2], v[3], w[3]);
+    a = Fr::add(a, t);
+  }
+  return a;
+}
+
+// NMAT = 2: out = Az | Bz | Cz (n rows each), x = the witness (x_mont = 0: standard form)
+// NMAT = 1: out = y (n rows), Montgomery in and out
+template <int NMAT, bool DICT>
+__global__ void __launch_bounds__(BLOCK) spmv_binned(SpmvBins bins, const uint32_t* __restrict__ ptr,
+                                                     const uint32_t* __restrict__ col, const u256* __restrict__ val,
+                                                     const uint32_t* __restrict__ vidx, const u256* __restrict__ x,
+                                                     const uint32_t* __restrict__ rows, uint32_t x_mont, uint32_t n,
+                                                     u256* __restrict__ out) {
+  uint32_t g = 0;
+  while (blockIdx.x >= bins.blk_off[g + 1]) ++g;   // wave-uniform: <= 6 steps
+  const uint32_t G = 1u << g;
+  const uint32_t slot = (blockIdx.x - bins.blk_off[g]) * (BLOCK >> g) + (threadIdx.x >> g);
+  const uint32_t lane = threadIdx.x & (G - 1);
+  const bool live = slot < bins.row_off[g + 1] - bins.row_off[g];
+  const uint32_t r = live ? rows[bins.row_off[g] + slot] : 0u;
+  u256 acc[NMAT];
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m) {
+    const uint32_t s = live ? ptr[(size_t)NMAT * r + m] : 0u;
+    const uint32_t e = live ? ptr[(size_t)NMAT * r + m + 1] : 0u;
+    u256 a = lane_dot<DICT>(s, e, lane, g, col, val, vidx, x);
+    for (uint32_t off = G >> 1; off; off >>= 1) a = Fr::add(a, shfl_xor_u256(a, (int)off));   // every lane takes part
+    acc[m] = a;
+  }
+  if (!live || lane) return;
+  if constexpr (NMAT == 2) {
+    if (!x_mont) {
+      acc[0] = Fr::to_mont(acc[0]);
+      acc[1] = Fr::to_mont(acc[1]);
+    }
+    out[r] = acc[0];
+    out[(size_t)n + r] = acc[1];
+    out[2 * (size_t)n + r] = Fr::mul(acc[0], acc[1]);
+  } else {
+    out[r] = acc[0];
+  }
+}
+
+struct Key256 {
+  uint64_t w[4];
+  bool operator==(const Key256& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+};
+struct Key256Hash {
+  size_t operator()(const Key256& k) const {
+    uint64_t h = k.w[0] * 0x9E3779B97F4A7C15ull;
+    h ^= (k.w[1] + 0xBF58476D1CE4E5B9ull) * 0x94D049BB133111EBull;
+    h ^= (k.w[2] >> 7) ^ (k.w[3] * 0xD6E8FEB86659FD93ull);
+    return (size_t)(h ^ (h >> 29));
+  }
+};
+
+}  // namespace
+
+struct g16_spmat {
+  int device = 0;
+  uint32_t nmat = 1, nrows = 0;
+  size_t nnz = 0, ndict = 0;   // ndict > 0: d_val holds the dictionary, d_vidx the per-entry indices
+  uint32_t *d_ptr = nullptr, *d_col = nullptr, *d_vidx = nullptr, *d_rows = nullptr;
+  u256* d_val = nullptr;
+  SpmvBins bins;
+};
+
+void g16_spmat_destroy(g16_spmat* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  for (void* p : {(void*)m->d_ptr, (void*)m->d_col, (void*)m->d_vidx, (void*)m->d_rows, (void*)m->d_val})
+    if (p) (void)hipFree(p);
+  delete m;
+}
+
+void g16_spmat_info(const g16_spmat* m, size_t out[8]) {
+  out[0] = m ? m->ndict : 0;
+  for (int g = 0; g < NBINS; ++g) out[1 + g] = m ? m->bins.row_off[g + 1] - m->bins.row_off[g] : 0;
+}
+
+// vrow[i] = nmat * row + matrix of entry i (< nmat * nrows, checked by the caller), col[i], val = 32 bytes at
+// val_base + i * val_stride.  The caller has made ctx's device current (CTX_ENTER).
+int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
+                         size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
+                         size_t val_stride, g16_spmat** out) {
+  *out = nullptr;
+  if (nnz >= (size_t(1) << 32) || (size_t)nmat * nrows >= (size_t(1) << 32) - 1) {
+    ctx->err = "sparse matrix too large (entry offsets are 32-bit)";
+    return G16_EINVAL;
+  }
+  auto at32 = [](const uint32_t* p, size_t stride, size_t i) {
+    return *(const uint32_t*)((const char*)p + i * stride);
+  };
+  const size_t nv = (size_t)nmat * nrows;
+  std::vector<uint32_t> ptr(nv + 1, 0);
+  for (size_t i = 0; i < nnz; ++i) ptr[at32(vrow, vrow_stride, i) + 1]++;
+  for (size_t v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
+  std::vector<uint32_t> cols(nnz ? nnz : 1), order(nnz ? nnz : 1);
+  {
+    std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
+    for (size_t i = 0; i < nnz; ++i) {
+      const uint32_t p = cur[at32(vrow, vrow_stride, i)]++;
+      cols[p] = at32(col, col_stride, i);
+      order[p] = (uint32_t)i;
+    }
+  }
+  // dictionary of the values (<= 65536 distinct ones and at least 8 entries per distinct value), else plain values
+  constexpr size_t DICT_MAX = 65536;
+  std::vector<uint32_t> vidx;
+  std::vector<u256> vals;
+  bool dict = nnz >= 1024 && g16_env().abc_dict != 0;
+  if (dict) {
+    std::unordered_map<Key256, uint32_t, Key256Hash> map;
+    map.reserve(4096);
+    vidx.resize(nnz);
+    for (size_t p = 0; p < nnz && dict; ++p) {
+      Key256 k;
+      memcpy(&k, (const char*)val_base + (size_t)order[p] * val_stride, 32);
+      auto it = map.find(k);
+      if (it == map.end()) {
+        if (map.size() >= DICT_MAX || map.size() * 8 > nnz) {
+          dict = false;
+          break;
+        }
+        it = map.emplace(k, (uint32_t)map.size()).first;
+        vals.resize(map.size());
+        memcpy(&vals[it->second], &k, 32);
+      }
+      vidx[p] = it->second;
+    }
+  }
+  if (!dict) {
+    vidx.clear();
+    vals.resize(nnz ? nnz : 1);
+    for (size_t p = 0; p < nnz; ++p) memcpy(&vals[p], (const char*)val_base + (size_t)order[p] * val_stride, 32);
+  }
+  // bins by the longer entry list of a row
+  g16_spmat* m = new (std::nothrow) g16_spmat();
+  if (!m) return G16_ENOMEM;
+  m->device = ctx->device;
+  m->nmat = nmat, m->nrows = nrows, m->nnz = nnz, m->ndict = dict ? vals.size() : 0;
+  std::vector<uint8_t> bin(nrows ? nrows : 1);
+  uint32_t cnt[NBINS] = {0};
+  for (uint32_t r = 0; r < nrows; ++r) {
+    uint32_t L = 0;
+    for (uint32_t k = 0; k < nmat; ++k) L = std::max(L, ptr[(size_t)nmat * r + k + 1] - ptr[(size_t)nmat * r + k]);
+    uint32_t g = 0;
+    while (g < NBINS - 1 && (4u << g) < L) ++g;
+    bin[r] = (uint8_t)g;
+    cnt[g]++;
+  }
+  m->bins.row_off[0] = m->bins.blk_off[0] = 0;
+  for (int g = 0; g < NBINS; ++g) {
+    m->bins.row_off[g + 1] = m->bins.row_off[g] + cnt[g];
+    const uint32_t per = BLOCK >> g;
+    m->bins.blk_off[g + 1] = m->bins.blk_off[g] + (cnt[g] + per - 1) / per;
+  }
+  std::vector<uint32_t> rows(nrows ? nrows : 1);
+  {
+    uint32_t cur[NBINS];
+    for (int g = 0; g < NBINS; ++g) cur[g] = m->bins.row_off[g];
+    for (uint32_t r = 0; r < nrows; ++r) rows[cur[bin[r]]++] = r;
+  }
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t {
+    if (hipMalloc(dst, bytes ? bytes : 4) != hipSuccess) {
+      ctx->err = "hipMalloc(sparse matrix) failed";
+      return G16_ENOMEM;
+    }
+    if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      ctx->err = "hipMemcpy(sparse matrix) failed";
+      return G16_EHIP;
+    }
+    return G16_OK;
+  };
+  int32_t rc = up((void**)&m->d_ptr, ptr.data(), ptr.size() * 4);
+  if (!rc) rc = up((void**)&m->d_col, cols.data(), nnz * 4);
+  if (!rc) rc = up((void**)&m->d_val, vals.data(), (dict ? vals.size() : nnz) * 32);
+  if (!rc && dict) rc = up((void**)&m->d_vidx, vidx.data(), nnz * 4);
+  if (!rc) rc = up((void**)&m->d_rows, rows.data(), (size_t)nrows * 4);
+  if (rc) {
+    g16_spmat_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return G16_OK;
+}
+
+// out = (nmat == 2 ? Az | Bz | Cz : y), device pointers, on the context's main stream
+int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out) {
+  const uint32_t nblk = m->bins.blk_off[NBINS];
+  if (!nblk) return G16_OK;
+  const char* name = m->nmat == 2 ? "abc_spmv" : "spmv";
+#define SPMV_LAUNCH(NM, DI)                                                                                          \
+  KLAUNCH(ctx, name, (spmv_binned<NM, DI>), nblk, BLOCK, 0, m->bins, m->d_ptr, m->d_col, m->d_val, m->d_vidx,         \
+          (const u256*)d_x, m->d_rows, x_mont, m->nrows, (u256*)d_out)
+  if (m->nmat == 2) {
+    if (m->ndict) SPMV_LAUNCH(2, true);
+    else SPMV_LAUNCH(2, false);
+  } else {
+    if (m->ndict) SPMV_LAUNCH(1, true);
+    else SPMV_LAUNCH(1, false);
+  }
+#undef SPMV_LAUNCH
+  HIPCHK(ctx, hipGetLastError());
+  return G16_OK;
+}
+
+// y = M x from triplets, host pointers: see include/g16hip.h
+extern "C" int32_t g16_spmv_fr(g16_ctx* ctx, const uint32_t* row, const uint32_t* col, const void* val, size_t nnz,
+                               const void* x, size_t ncols, size_t nrows, void* y) {
+  if (!ctx) return G16_EINVAL;
+  if ((nnz && (!row || !col || !val)) || (ncols && !x) || (nrows && !y) || nrows >= (size_t(1) << 31) ||
+      ncols >= (size_t(1) << 32)) {
+    ctx->err = "bad argument";
+    return G16_EINVAL;
+  }
+  for (size_t i = 0; i < nnz; ++i)
+    if (row[i] >= nrows || col[i] >= ncols) {
+      ctx->err = "sparse entry out of range";
+      return G16_EINVAL;
+    }
+  if (!nrows) return G16_OK;
+  CTX_ENTER(ctx);
+  g16_spmat* m = nullptr;
+  int32_t rc = g16_spmat_create(ctx, 1, (uint32_t)nrows, nnz, row, 4, col, 4, val, 32, &m);
+  if (rc) return rc;
+  void *d_x = nullptr, *d_y = nullptr;
+  auto done = [&](int32_t code) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_x) (void)hipFree(d_x);
+    if (d_y) (void)hipFree(d_y);
+    g16_spmat_destroy(m);
+    return code;
+  };
+  if (hipMalloc(&d_x, (ncols ? ncols : 1) * 32) != hipSuccess || hipMalloc(&d_y, nrows * 32) != hipSuccess) {
+    ctx->err = "hipMalloc(spmv vectors) failed";
+    return done(G16_ENOMEM);
+  }
+  if (ncols && hipMemcpyAsync(d_x, x, ncols * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    ctx->err = "hipMemcpy(x) failed";
+    return done(G16_EHIP);
+  }
+  if ((rc = g16_spmat_apply(ctx, m, d_x, 1, d_y))) return done(rc);
+  if (hipMemcpyAsync(y, d_y, nrows * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    ctx->err = "spmv: copy back failed";
+    return done(G16_EHIP);
+  }
+  return done(G16_OK);
+}

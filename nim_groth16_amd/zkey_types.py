@@ -53,10 +53,34 @@ class _Coeff(ctypes.Structure):      # g16_coeff (include/g16hip.h)
                 ("reserved", ctypes.c_uint32), ("value", ctypes.c_uint8 * 32)]
 
 
+COEFF_DTYPE = [("m", "<u4"), ("r", "<u4"), ("c", "<u4"), ("x", "<u4"), ("v", "u1", (32,))]   # g16_coeff
+
+
+class CoeffArray:
+    """ZKey.coeffs as ONE numpy record array in the g16_coeff layout (large circuits: 10^7 entries as Python tuples
+    would take gigabytes).  Iterates as the same (matrix, row, col, Fr bytes) tuples as the list form."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def __len__(self):
+        return len(self.arr)
+
+    def __iter__(self):
+        for rec in self.arr:
+            yield (int(rec["m"]), int(rec["r"]), int(rec["c"]), rec["v"].tobytes())
+
+    def __getitem__(self, i):
+        rec = self.arr[i]
+        return (int(rec["m"]), int(rec["r"]), int(rec["c"]), rec["v"].tobytes())
+
+
 def packCoeffs(coeffs) -> bytes:
     import numpy as np
+    if isinstance(coeffs, CoeffArray):
+        return coeffs.arr.tobytes()
     n = len(coeffs)
-    arr = np.zeros(n, dtype=np.dtype([("m", "<u4"), ("r", "<u4"), ("c", "<u4"), ("x", "<u4"), ("v", "u1", (32,))]))
+    arr = np.zeros(n, dtype=np.dtype(COEFF_DTYPE))
     if n:
         arr["m"] = [c[0] for c in coeffs]
         arr["r"] = [c[1] for c in coeffs]

@@ -37,6 +37,18 @@ for kw in (dict(), dict(zero_pct=0, one_pct=0, lin_pct=60)):
     pr = generateProofWithMask(0, False, zk, Witness("bn128", m + 2, wb), mask, ctx, pkey=pk)
     check_gpu_proof(orc, zk, wit, wb, mask.r, mask.s, (pr.pi_a, pr.pi_b, pr.pi_c), ctx)
     pk.destroy()
+from nim_groth16_amd.synthetic import poseidonMerkle
+r1cs, wit = poseidonMerkle(10, seed=4)                          # rows of 1..25 terms: groups of 1..8 lanes in buildABC
+rng = SplitMix64(5)
+zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
+pk = loadProvingKey(zk, ctx)
+wb = F.frSeqToMontBytes(wit)
+mask = Mask(rng.fr(), rng.fr())
+pr = generateProofWithMask(0, False, zk, Witness("bn128", len(wit), wb), mask, ctx, pkey=pk)
+check_gpu_proof(orc, zk, wit, wb, mask.r, mask.s, (pr.pi_a, pr.pi_b, pr.pi_c), ctx)
+import os
+assert (pk.abc_info()["dict_values"] > 0) == (os.environ.get("G16_ABC_DICT", "1") != "0")
+pk.destroy()
 for group, n in ((1, 3000), (2, 700), (1, 64), (1, 1)):
     ks = I.uniform_scalars(n, 11)
     sc = I.circom_like_scalars(n, 12)
@@ -84,6 +96,7 @@ KNOBS = [
     {"G16_TAIL_QUAD": "1", "G16_RED_CHUNK": "8", "G16_G2_FIRST": "2", "G16_TABLE_WINDOW": "16"},
     {"G16_TAIL_QUAD": "1", "G16_RED_CHUNK": "2", "G16_MTAB": "1"},       # quad reduce2 in front of the one-lane merged fold
     {"G16_TAIL_QUAD": "1", "G16_MSM_WINDOW": "16"},                     # 2048 chunks per window: the 128-slot G1 variant
+    {"G16_ABC_DICT": "0"},                                      # buildABC on 32-byte values although a dictionary would do
 ]
 
 
