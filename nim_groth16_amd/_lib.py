@@ -429,10 +429,11 @@ class ProvingKey:
 
     def abc_info(self) -> dict:
         """shape of the A / B matrices as buildABC runs them (g16_pkey_abc_info)"""
-        out = (ctypes.c_size_t * 9)()
+        out = (ctypes.c_size_t * 11)()
         self.ctx._check(self.ctx._lib.g16_pkey_abc_info(self._h, out))
         v = list(out)
-        return {"ncoeffs": v[0], "dict_values": v[1], "rows_per_group_size": {1 << g: v[2 + g] for g in range(7)}}
+        names = ("L<=1", "L=2", "L<=4", "L<=8", "L<=16", "L<=32", "L<=64", "L<=128", "L>128")
+        return {"ncoeffs": v[0], "dict_values": v[1], "rows_by_terms": dict(zip(names, v[2:]))}
 
     def build_abc(self, witness: bytes, mont: bool = True, ctx=None):
         c = ctx or self.ctx

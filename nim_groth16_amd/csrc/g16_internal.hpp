@@ -302,7 +302,7 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
                          size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
                          size_t val_stride, g16_spmat** out);
 void g16_spmat_destroy(g16_spmat* m);
-void g16_spmat_info(const g16_spmat* m, size_t out[8]);   // dictionary size (0: plain values), rows per bin
+void g16_spmat_info(const g16_spmat* m, size_t out[10]);   // dictionary size (0: plain values), virtual rows per bin
 int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out);
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse);
 // computeSnarkjsScalarCoeffs (flavour 1, prover.nim:158-181) / computeQuotientPointwise (flavour 0, :118-148)

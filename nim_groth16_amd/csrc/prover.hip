@@ -136,7 +136,7 @@ extern "C" int32_t g16_pkey_inf_counts(const g16_pkey* k, size_t out[8]) {
   return G16_OK;
 }
 
-extern "C" int32_t g16_pkey_abc_info(const g16_pkey* k, size_t out[9]) {
+extern "C" int32_t g16_pkey_abc_info(const g16_pkey* k, size_t out[11]) {
   if (!k || !out) return G16_EINVAL;
   out[0] = k->ncoeffs;
   g16_spmat_info(k->abc, out + 1);

@@ -7,17 +7,22 @@
 // one, and a wave is then as slow as its longest row while its lanes read 32-byte values at strides of a kilobyte.
 //
 // Layout, built once per key (the matrices are per-circuit constants like the point sets):
-//   * entries in row order, the A entries of row r followed by its B entries: ptr[2 r], ptr[2 r + 1], ptr[2 r + 2]
-//     (one matrix: ptr[r], ptr[r + 1]); col / val arrays parallel to it
-//   * rows sorted into seven BINS by L = the longer of their (up to two) entry lists: bin g serves a row with a GROUP
-//     of 2^g lanes, 4 * 2^(g-1) < L <= 4 * 2^g (bin 0: L <= 4, incl. the empty rows of the padded domain; bin 6: all
-//     longer rows, looping).  Lane j of a group takes entries j, j + G, j + 2G, j + 3G: every load instruction of a
-//     group reads G consecutive entries, and all lanes of a wave have the same trip count.
+//   * a VIRTUAL ROW per (row, matrix): v = 2 row + matrix for a key's A and B (v = row for one matrix); entries in
+//     virtual-row order (ptr[v], ptr[v + 1]) with col / val arrays parallel to it.  A and B of one constraint are
+//     balanced separately: x5 = x4 * lc has one A term and twenty B terms.
+//   * virtual rows sorted into nine BINS by their length L, every wave running ONE code path at ONE trip count:
+//       bin 0: L <= 1 (incl. the empty rows of the padded domain)   one lane, one Montgomery product
+//       bin 1: L == 2                                               one lane, one fused two-term dot product
+//       bin 2: L == 3, 4                                            one lane, one fused four-term dot product
+//       bin 2 + g, g = 1..6: 4 * 2^(g-1) < L <= 4 * 2^g              a GROUP of 2^g lanes, four terms per lane
+//       (the last bin takes all longer rows, looping).  Lane j of a group takes entries j, j + G, j + 2G, j + 3G:
+//     every load instruction of a group reads G consecutive entries.
 //   * a lane's (up to) four products are ONE Montgomery dot product (Fr::mul4: 4 x 64 multiply-adds + one 64-mad
 //     reduction instead of four); the group then adds its lanes' sums with log2 G cross-lane steps (ds_bpermute, no
-//     LDS memory), lane 0 forms Cz = Az * Bz (prover.nim:69-72) and writes the row.
-//   * a standard-form witness (raw .wtns values) is multiplied as it is -- (v R) w / R = v w -- and the row sum is
-//     brought to Montgomery form once per row, not once per entry.
+//     LDS memory) and lane 0 writes the sum.
+//   * buildABC's pointwise Cz = Az * Bz (prover.nim:69-72) is a second, streaming kernel.  A standard-form witness
+//     (raw .wtns values) is multiplied as it is -- (v R) w / R = v w -- and that kernel brings Az, Bz to Montgomery form:
+//     once per row, not once per entry.
 //   * value DICTIONARY: circuit coefficients come from a small set (+-1, MDS entries, round constants); when a key's
 //     non-zeros hold <= 65536 distinct values the entry stream is (col, value index) = 8 bytes instead of 36 and the
 //     value table stays in L2.
@@ -32,12 +37,22 @@ using namespace g16;
 
 namespace {
 
-constexpr int NBINS = 7;
+constexpr int NBINS = 9;
 constexpr uint32_t BLOCK = 256;
 
+// lanes per virtual row of bin b = 2^bin_glog(b)
+__host__ __device__ constexpr uint32_t bin_glog(uint32_t b) { return b < 3 ? 0u : b - 2; }
+inline uint32_t bin_of(uint32_t L) {
+  if (L <= 1) return 0;
+  if (L == 2) return 1;
+  uint32_t b = 2;
+  while (b < NBINS - 1 && (4u << bin_glog(b)) < L) ++b;
+  return b;
+}
+
 struct SpmvBins {
-  uint32_t row_off[NBINS + 1];   // bin g: rows[row_off[g] .. row_off[g + 1])
-  uint32_t blk_off[NBINS + 1];   // ... served by workgroups blk_off[g] .. blk_off[g + 1), 256 >> g rows each
+  uint32_t row_off[NBINS + 1];   // bin b: rows[row_off[b] .. row_off[b + 1])
+  uint32_t blk_off[NBINS + 1];   // ... served by workgroups blk_off[b] .. blk_off[b + 1), 256 >> bin_glog(b) rows each
 };
 
 __device__ __forceinline__ u256 shfl_xor_u256(const u256& a, int off) {
@@ -47,72 +62,77 @@ __device__ __forceinline__ u256 shfl_xor_u256(const u256& a, int off) {
   return r;
 }
 
-// sum over the entries [s, e) this lane owns (lane, lane + G, ...) of val * x[col]
 template <bool DICT>
+__device__ __forceinline__ void load_entry(uint32_t idx, const uint32_t* __restrict__ col, const u256* __restrict__ val,
+                                           const uint32_t* __restrict__ vidx, const u256* __restrict__ x, u256& v, u256& w) {
+  v = DICT ? val[vidx[idx]] : val[idx];
+  w = x[col[idx]];
+}
+
+// sum over the entries [s, e) this lane owns (lane, lane + G, ...) of val * x[col]; K = the bin's terms per trip
+template <bool DICT, int K>
 __device__ __forceinline__ u256 lane_dot(uint32_t s, uint32_t e, uint32_t lane, uint32_t g,
                                          const uint32_t* __restrict__ col, const u256* __restrict__ val,
                                          const uint32_t* __restrict__ vidx, const u256* __restrict__ x) {
   const uint32_t G = 1u << g;
   u256 a = Fr::zero();
-  for (uint32_t i = s + lane; i < e; i += 4 * G) {
-    const uint32_t k = (e - i + G - 1) >> g;   // entries of this trip: >= 1
-    u256 v[4], w[4];
+  for (uint32_t i = s + lane; i < e; i += K * G) {
+    u256 v[K], w[K];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if ((uint32_t)j < k) {
-        const uint32_t idx = i + j * G;
-        v[j] = DICT ? val[vidx[idx]] : val[idx];
-        w[j] = x[col[idx]];
+    for (int j = 0; j < K; ++j) {
+      const uint32_t idx = i + j * G;
+      if (j == 0 || idx < e) {
+        load_entry<DICT>(idx, col, val, vidx, x, v[j], w[j]);
       } else {
         v[j] = Fr::zero();
         w[j] = Fr::zero();
       }
     }
     u256 t;
-    if (k == 1) t = Fr::mul(v[0], w[0]);
-    else if (k == 2) t = Fr::mul2(v[0], w[0], v[1], w[1]);
+    if constexpr (K == 1) t = Fr::mul(v[0], w[0]);
+    else if constexpr (K == 2) t = Fr::mul2(v[0], w[0], v[1], w[1]);
     else t = Fr::mul4(v[0], w[0], v[1], w[1], v[2], w[2], v[3], w[3]);
     a = Fr::add(a, t);
   }
   return a;
 }
 
-// NMAT = 2: out = Az | Bz | Cz (n rows each), x = the witness (x_mont = 0: standard form)
-// NMAT = 1: out = y (n rows), Montgomery in and out
+// y[(v % NMAT) * n + v / NMAT] = sum over the entries of virtual row v of val * x[col]
 template <int NMAT, bool DICT>
 __global__ void __launch_bounds__(BLOCK) spmv_binned(SpmvBins bins, const uint32_t* __restrict__ ptr,
                                                      const uint32_t* __restrict__ col, const u256* __restrict__ val,
                                                      const uint32_t* __restrict__ vidx, const u256* __restrict__ x,
-                                                     const uint32_t* __restrict__ rows, uint32_t x_mont, uint32_t n,
+                                                     const uint32_t* __restrict__ rows, uint32_t n,
                                                      u256* __restrict__ out) {
-  uint32_t g = 0;
-  while (blockIdx.x >= bins.blk_off[g + 1]) ++g;   // wave-uniform: <= 6 steps
-  const uint32_t G = 1u << g;
-  const uint32_t slot = (blockIdx.x - bins.blk_off[g]) * (BLOCK >> g) + (threadIdx.x >> g);
+  uint32_t b = 0;
+  while (blockIdx.x >= bins.blk_off[b + 1]) ++b;   // wave-uniform: <= 8 steps
+  const uint32_t g = bin_glog(b), G = 1u << g;
+  const uint32_t slot = (blockIdx.x - bins.blk_off[b]) * (BLOCK >> g) + (threadIdx.x >> g);
   const uint32_t lane = threadIdx.x & (G - 1);
-  const bool live = slot < bins.row_off[g + 1] - bins.row_off[g];
-  const uint32_t r = live ? rows[bins.row_off[g] + slot] : 0u;
-  u256 acc[NMAT];
-#pragma unroll
-  for (int m = 0; m < NMAT; ++m) {
-    const uint32_t s = live ? ptr[(size_t)NMAT * r + m] : 0u;
-    const uint32_t e = live ? ptr[(size_t)NMAT * r + m + 1] : 0u;
-    u256 a = lane_dot<DICT>(s, e, lane, g, col, val, vidx, x);
-    for (uint32_t off = G >> 1; off; off >>= 1) a = Fr::add(a, shfl_xor_u256(a, (int)off));   // every lane takes part
-    acc[m] = a;
+  const bool live = slot < bins.row_off[b + 1] - bins.row_off[b];
+  const uint32_t v = live ? rows[bins.row_off[b] + slot] : 0u;
+  const uint32_t s = live ? ptr[v] : 0u;
+  const uint32_t e = live ? ptr[v + 1] : 0u;
+  u256 a;
+  if (b == 0) a = lane_dot<DICT, 1>(s, e, lane, g, col, val, vidx, x);
+  else if (b == 1) a = lane_dot<DICT, 2>(s, e, lane, g, col, val, vidx, x);
+  else a = lane_dot<DICT, 4>(s, e, lane, g, col, val, vidx, x);
+  for (uint32_t off = G >> 1; off; off >>= 1) a = Fr::add(a, shfl_xor_u256(a, (int)off));   // every lane takes part
+  if (live && lane == 0) out[(size_t)(v % NMAT) * n + v / NMAT] = a;
+}
+
+// Cz = Az * Bz (prover.nim:69-72); x_mont == 0: the sums are in standard form (a .wtns witness): Az, Bz to Montgomery first
+__global__ void __launch_bounds__(BLOCK) abc_pointwise_cz(u256* __restrict__ abc, uint32_t x_mont, uint32_t n) {
+  const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= n) return;
+  u256 a = abc[r], b = abc[(size_t)n + r];
+  if (!x_mont) {
+    a = Fr::to_mont(a);
+    b = Fr::to_mont(b);
+    abc[r] = a;
+    abc[(size_t)n + r] = b;
   }
-  if (!live || lane) return;
-  if constexpr (NMAT == 2) {
-    if (!x_mont) {
-      acc[0] = Fr::to_mont(acc[0]);
-      acc[1] = Fr::to_mont(acc[1]);
-    }
-    out[r] = acc[0];
-    out[(size_t)n + r] = acc[1];
-    out[2 * (size_t)n + r] = Fr::mul(acc[0], acc[1]);
-  } else {
-    out[r] = acc[0];
-  }
+  abc[2 * (size_t)n + r] = Fr::mul(a, b);
 }
 
 struct Key256 {
@@ -147,9 +167,9 @@ void g16_spmat_destroy(g16_spmat* m) {
   delete m;
 }
 
-void g16_spmat_info(const g16_spmat* m, size_t out[8]) {
+void g16_spmat_info(const g16_spmat* m, size_t out[1 + 9]) {
   out[0] = m ? m->ndict : 0;
-  for (int g = 0; g < NBINS; ++g) out[1 + g] = m ? m->bins.row_off[g + 1] - m->bins.row_off[g] : 0;
+  for (int b = 0; b < NBINS; ++b) out[1 + b] = m ? m->bins.row_off[b + 1] - m->bins.row_off[b] : 0;
 }
 
 // vrow[i] = nmat * row + matrix of entry i (< nmat * nrows, checked by the caller), col[i], val = 32 bytes at
@@ -208,32 +228,29 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
     vals.resize(nnz ? nnz : 1);
     for (size_t p = 0; p < nnz; ++p) memcpy(&vals[p], (const char*)val_base + (size_t)order[p] * val_stride, 32);
   }
-  // bins by the longer entry list of a row
+  // bins by the length of a virtual row
   g16_spmat* m = new (std::nothrow) g16_spmat();
   if (!m) return G16_ENOMEM;
   m->device = ctx->device;
   m->nmat = nmat, m->nrows = nrows, m->nnz = nnz, m->ndict = dict ? vals.size() : 0;
-  std::vector<uint8_t> bin(nrows ? nrows : 1);
+  std::vector<uint8_t> bin(nv ? nv : 1);
   uint32_t cnt[NBINS] = {0};
-  for (uint32_t r = 0; r < nrows; ++r) {
-    uint32_t L = 0;
-    for (uint32_t k = 0; k < nmat; ++k) L = std::max(L, ptr[(size_t)nmat * r + k + 1] - ptr[(size_t)nmat * r + k]);
-    uint32_t g = 0;
-    while (g < NBINS - 1 && (4u << g) < L) ++g;
-    bin[r] = (uint8_t)g;
-    cnt[g]++;
+  for (size_t v = 0; v < nv; ++v) {
+    const uint32_t b = bin_of(ptr[v + 1] - ptr[v]);
+    bin[v] = (uint8_t)b;
+    cnt[b]++;
   }
   m->bins.row_off[0] = m->bins.blk_off[0] = 0;
-  for (int g = 0; g < NBINS; ++g) {
-    m->bins.row_off[g + 1] = m->bins.row_off[g] + cnt[g];
-    const uint32_t per = BLOCK >> g;
-    m->bins.blk_off[g + 1] = m->bins.blk_off[g] + (cnt[g] + per - 1) / per;
+  for (int b = 0; b < NBINS; ++b) {
+    m->bins.row_off[b + 1] = m->bins.row_off[b] + cnt[b];
+    const uint32_t per = BLOCK >> bin_glog(b);
+    m->bins.blk_off[b + 1] = m->bins.blk_off[b] + (cnt[b] + per - 1) / per;
   }
-  std::vector<uint32_t> rows(nrows ? nrows : 1);
+  std::vector<uint32_t> rows(nv ? nv : 1);
   {
     uint32_t cur[NBINS];
-    for (int g = 0; g < NBINS; ++g) cur[g] = m->bins.row_off[g];
-    for (uint32_t r = 0; r < nrows; ++r) rows[cur[bin[r]]++] = r;
+    for (int b = 0; b < NBINS; ++b) cur[b] = m->bins.row_off[b];
+    for (size_t v = 0; v < nv; ++v) rows[cur[bin[v]]++] = (uint32_t)v;
   }
   auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t {
     if (hipMalloc(dst, bytes ? bytes : 4) != hipSuccess) {
@@ -250,7 +267,7 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
   if (!rc) rc = up((void**)&m->d_col, cols.data(), nnz * 4);
   if (!rc) rc = up((void**)&m->d_val, vals.data(), (dict ? vals.size() : nnz) * 32);
   if (!rc && dict) rc = up((void**)&m->d_vidx, vidx.data(), nnz * 4);
-  if (!rc) rc = up((void**)&m->d_rows, rows.data(), (size_t)nrows * 4);
+  if (!rc) rc = up((void**)&m->d_rows, rows.data(), nv * 4);
   if (rc) {
     g16_spmat_destroy(m);
     return rc;
@@ -263,13 +280,13 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
 int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out) {
   const uint32_t nblk = m->bins.blk_off[NBINS];
   if (!nblk) return G16_OK;
-  const char* name = m->nmat == 2 ? "abc_spmv" : "spmv";
 #define SPMV_LAUNCH(NM, DI)                                                                                          \
-  KLAUNCH(ctx, name, (spmv_binned<NM, DI>), nblk, BLOCK, 0, m->bins, m->d_ptr, m->d_col, m->d_val, m->d_vidx,         \
-          (const u256*)d_x, m->d_rows, x_mont, m->nrows, (u256*)d_out)
+  KLAUNCH(ctx, NM == 2 ? "abc_spmv" : "spmv", (spmv_binned<NM, DI>), nblk, BLOCK, 0, m->bins, m->d_ptr, m->d_col,     \
+          m->d_val, m->d_vidx, (const u256*)d_x, m->d_rows, m->nrows, (u256*)d_out)
   if (m->nmat == 2) {
     if (m->ndict) SPMV_LAUNCH(2, true);
     else SPMV_LAUNCH(2, false);
+    KLAUNCH(ctx, "abc_cz", abc_pointwise_cz, (m->nrows + BLOCK - 1) / BLOCK, BLOCK, 0, (u256*)d_out, x_mont, m->nrows);
   } else {
     if (m->ndict) SPMV_LAUNCH(1, true);
     else SPMV_LAUNCH(1, false);

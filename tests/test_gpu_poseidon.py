@@ -36,7 +36,9 @@ def test_spmv_against_python_ints(ctx):
             for _ in range(L):
                 row.append(r), col.append(rng.next() % ncols)
                 val.append(pool[rng.next() % len(pool)] if few else rng.fr())
-        row += [5, 5], col += [3, 3], val += [7, 9]                       # duplicates add up
+        row += [5, 5]                                                     # duplicates add up
+        col += [3, 3]
+        val += [7, 9]
         perm = np.random.default_rng(1).permutation(len(row))             # triplets in any order
         row, col, val = (np.array(a, dtype=object)[perm] for a in (row, col, val))
         want = [0] * nrows
@@ -98,8 +100,9 @@ def test_build_abc_2p18_every_row_vs_c_oracle_and_full_proof_bit_exact(ctx, orc)
         info = pk.abc_info()
         assert info["ncoeffs"] == len(zk.coeffs) > 10 << log2n
         assert 0 < info["dict_values"] < 1000                       # MDS entries, round constants, +-1
-        g = info["rows_per_group_size"]
-        assert sum(g.values()) == 1 << log2n and g[1] > 0 and g[2] > 0 and g[4] > 0 and g[8] > 0 and g[64] == 0
+        g = info["rows_by_terms"]           # rows of A and of B, binned separately
+        assert sum(g.values()) == 2 << log2n and min(g[k] for k in ("L<=1", "L=2", "L<=4", "L<=8", "L<=16", "L<=32")) > 0
+        assert g["L<=64"] == g["L<=128"] == g["L>128"] == 0
         wb = F.frSeqToMontBytes(wit)
         want = orc.build_abc(packCoeffs(zk.coeffs), wb, log2n)
         assert pk.build_abc(wb) == want
@@ -138,7 +141,7 @@ def test_build_abc_rows_longer_than_a_wave(ctx, orc):
     pk = loadProvingKey(zk, ctx)
     try:
         info = pk.abc_info()
-        assert info["dict_values"] == 0 and info["rows_per_group_size"][64] == 2
+        assert info["dict_values"] == 0 and info["rows_by_terms"]["L>128"] == 2 and info["rows_by_terms"]["L<=128"] == 1
         wb = F.frSeqToMontBytes(wit)
         assert pk.build_abc(wb) == orc.build_abc(packCoeffs(zk.coeffs), wb, 6)
     finally:
