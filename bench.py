@@ -71,6 +71,11 @@ def parse_args(argv=None):
     ap.add_argument("--quotient", choices=["tasks", "replicated"], default="tasks",
                     help="shard mode: the three coset pipelines of the quotient on three different ranks + three "
                          "scatters of the slices (tasks), or recomputed by every rank (replicated)")
+    ap.add_argument("--no-poseidon-shape", action="store_true",
+                    help="skip the extra key value_poseidon_shape (N = 1, replica mode: a second key, a Poseidon-shaped "
+                         "Merkle circuit of the same domain, ~15 s of setup + one more oracle proof)")
+    ap.add_argument("--inject-failure", default="", metavar="RANK[:AFTER]",
+                    help="test hook: that rank raises after AFTER proofs (dry run: before its first collective)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduction plumbing only (gloo, no GPU, no proofs): what the CPU test "
                          "of the multi-rank launch path runs; prints a line with value 0 and dry_run true")
@@ -172,29 +177,51 @@ def main(argv=None):
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    # Everything between the rendezvous and its teardown runs under one guard: a failure on ANY rank (a worker
-    # error, a library error) is shared through an all-reduced flag before the next collective, so that every rank
-    # leaves with a non-zero code instead of waiting in a barrier for a rank that is gone.
+    # A failure on ANY rank (a worker error, a library error, a proof that differs) ends THAT rank at once: `FAIL ...` on
+    # stderr, exit code 1, no further collective.  torch.distributed.run then tears the other ranks down and the launch
+    # returns non-zero (the `quit()` convention of cli/cli_main.nim:187-222).  Rounds 3-4 shared the failure through an
+    # all-reduced flag instead -- but the healthy ranks are by then inside a DIFFERENT collective (the next proof's
+    # scatter / all-gather, or a barrier), the flag pairs with a mismatched operation and every rank waits forever
+    # (profiles/r05_failpath_old_one_rank_fails_hangs.err.txt).
     state = {}
-    err = None
     try:
         measure(args, rank, world, local, dist, coll_dev, state)
-    except BaseException as e:       # noqa: BLE001 -- re-raised below, after the other ranks have been told
-        err = e
+    except BaseException as e:       # noqa: BLE001
+        fail_fast(e, rank, world)
     if dist is not None:
-        try:
-            flag = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if err is None and flag.item() > 0:
-                err = SystemExit("FAIL: another rank failed")
-        finally:
-            dist.destroy_process_group()
-    if err is not None:
-        raise err if isinstance(err, SystemExit) else SystemExit(f"FAIL: {err!r}")
+        dist.destroy_process_group()
     # The oracle gate and the CPU baseline run AFTER the process group is gone: 3 x ~14 s of CPU work on rank 0
     # during which no other rank idles inside a collective.
     if rank == 0:
         finish_rank0(args, world, state)
+
+
+def fail_fast(e, rank, world):
+    """`FAIL (rank r): ...` + the traceback on stderr, then leave with code 1 WITHOUT interpreter teardown when other
+    ranks exist: destructors of contexts with proofs in flight, or of a process group with collectives pending, have
+    nothing to wait for that will ever arrive."""
+    import traceback
+    msg = str(e) if isinstance(e, SystemExit) else repr(e)
+    if not msg.startswith("FAIL"):
+        msg = "FAIL: " + msg
+    sys.stderr.write(f"{msg}  [rank {rank} of {world}]\n")
+    if not isinstance(e, SystemExit):
+        traceback.print_exception(type(e), e, e.__traceback__, file=sys.stderr)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    if world > 1:
+        os._exit(1)
+    raise SystemExit(msg)
+
+
+def injected_failure(args, rank, done):
+    """--inject-failure RANK[:AFTER]: that rank fails once `AFTER` (default 2) of its timed-path proofs are done (tests of
+    the failure path; `done` = None in the dry run: fail before the first collective)"""
+    if not args.inject_failure:
+        return
+    r, _, after = args.inject_failure.partition(":")
+    if int(r) == rank and (done is None or done >= int(after or 2)):
+        raise RuntimeError(f"injected failure on rank {rank}")
 
 
 def measure(args, rank, world, local, dist, coll_dev, state):
@@ -262,6 +289,7 @@ def measure(args, rank, world, local, dist, coll_dev, state):
                 if p is not None:
                     keep(done, p)
                     done += 1
+                    injected_failure(args, rank, done)
             for p in sp.collect():
                 keep(done, p)
                 done += 1
@@ -270,17 +298,18 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     else:
         ctxs = [ctx] + [Context(local) for _ in range(inflight - 1)]      # ONE key, `inflight` contexts
 
-        def step(i, lane=0, hbm=False):
-            w = (d_w if hbm else h_w)[i % NWITNESS]
-            return pkey.prove(w.data_ptr(), mont=False, r=rb, s=sb, device=hbm, ctx=ctxs[lane])
+        def step(i, lane=0, hbm=False, pk=None, ws=None):
+            ws = ws or (d_w if hbm else h_w)
+            return (pk or pkey).prove(ws[i % len(ws)].data_ptr(), mont=False, r=rb, s=sb, device=hbm, ctx=ctxs[lane])
 
-        def run(count, hbm=False):
+        def run(count, hbm=False, pk=None, ws=None, sink=keep):
             """`count` proofs, `inflight` at a time: worker j proves steps j, j+inflight, ... on its own context"""
             def work(j):
                 try:
                     torch.cuda.set_device(local)   # a new host thread starts on device 0 (the library sets it per call too)
                     for i in range(j, count, inflight):
-                        keep(i, step(i, j, hbm))
+                        sink(i, step(i, j, hbm, pk, ws))
+                        injected_failure(args, rank, i + 1)
                 except BaseException as e:      # a G16Error in a worker must fail the run, not just end the thread
                     with plock:
                         errors.append(f"worker {j}: {e!r}")
@@ -344,6 +373,8 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     barrier()
     if shard:
         sp.close()
+    if not shard and world == 1 and not args.no_poseidon_shape:
+        state["poseidon"] = poseidon_shape(args, ctx, run, step, barrier, rb, sb)
 
     state.update(zkey=zkey, wits=wits, mask=mask, proofs=proofs, ctx=ctx, value=value, dt=dt, value_other=value_other,
                  lat_ms=lat_ms, inflight=inflight, shard=shard, value_runs=[round(proofs_done / t, 4) for t in runs])
@@ -410,9 +441,8 @@ def measure(args, rank, world, local, dist, coll_dev, state):
                 **{k: v["total_ms"] / v["calls"] for k, v in rep_other.items()}}
         if "msm_accum_g1" in both and "msm_accum_g2" in both:
             acc_ms = 4 * both["msm_accum_g1"] + both["msm_accum_g2"]
-            step_ms = dt / args.steps * 1e3 * (world if not shard else 1)     # per proof on THIS GPU
             extra["accum_ms_per_proof"] = round(acc_ms, 4)
-            extra["overlap_efficiency"] = round(acc_ms / step_ms, 4)
+            extra["overlap_efficiency"] = overlap_efficiency(acc_ms, dt, args.steps)
     g1 = sum(v["total_ms"] for v in rep1.values()) / reps
     if grp == 1:
         nwin = 254 // c + 1                   # W tables = nwin windows x (1 or 2) multiplier tables
@@ -430,6 +460,73 @@ def measure(args, rank, world, local, dist, coll_dev, state):
     extra["standalone_msm_wall_ms"] = round(msm_wall, 4)
     extra["roofline_valu"] = valu_roofline(dom, iso, clock_ghz, static)
     state.update(roof=roof, extra=extra)
+
+
+def overlap_efficiency(accum_ms_per_proof, region_s, steps):
+    """isolated accumulate time of one proof over the time THIS GPU spends per proof.  In replica mode every rank proves
+    `steps` proofs in the region, in shard mode all ranks work on each of the `steps` proofs: either way a GPU's time
+    per proof is region / steps -- the same expression as `ms_per_step`, for any world size."""
+    return round(accum_ms_per_proof / (region_s / steps * 1e3), 4)
+
+
+def poseidon_shape(args, ctx, run, step, barrier, rb, sb):
+    """The same timed protocol on BASELINE config 5's workload SHAPE: a Poseidon-shaped Merkle-inclusion circuit
+    (nim_groth16_amd/synthetic.py: rows of 1..25 terms, ncoeffs ~ 12 n, a third of the wires absent from B -- not a
+    circom artefact: none can be produced here), same domain, same toxic waste, its own key.  Reported as the extra key
+    `value_poseidon_shape`; `value` is untouched."""
+    import torch
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd import loadProvingKey
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import SplitMix64, poseidonMerkle
+    t0 = time.time()
+    r1cs, wit = poseidonMerkle(args.log2n, seed=4)
+    rng = SplitMix64(5)
+    zk = fakeCircuitSetup(r1cs, ToxicWaste(*[rng.fr() for _ in range(5)]), 1, ctx)
+    pk = loadProvingKey(zk, ctx)
+    ws = F.frSeqToStdBytes(wit)
+    hw = torch.empty(len(ws), dtype=torch.uint8).pin_memory()
+    hw.copy_(torch.frombuffer(bytearray(ws), dtype=torch.uint8))
+    log(f"[bench] Poseidon-shaped circuit, setup, key upload: {time.time()-t0:.1f}s")
+    last = [None]
+
+    def sink(i, p):
+        if last[0] is not None and last[0] != p:
+            raise RuntimeError("two proofs of the Poseidon-shaped witness differ")
+        last[0] = p
+    steps = max(args.steps, 48)
+    run(12, pk=pk, ws=[hw], sink=sink)
+    vals = []
+    for _ in range(3):
+        barrier()
+        t1 = time.perf_counter()
+        run(steps, pk=pk, ws=[hw], sink=sink)
+        barrier()
+        vals.append(steps / (time.perf_counter() - t1))
+    t1 = time.perf_counter()
+    for i in range(3):
+        step(i, pk=pk, ws=[hw])
+    lat = (time.perf_counter() - t1) / 3 * 1e3
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    for _ in range(5):
+        pk.build_abc(ws, mont=False)
+    rep = ctx.profile_report()
+    ctx.profile(False)
+    info, inf = pk.abc_info(), pk.inf_counts()
+    pk.destroy()
+    return {"zkey": zk, "wit": wit, "proof": last[0],
+            "line": {"value": round(sorted(vals)[1], 4), "unit": "proofs/s", "runs": [round(v, 4) for v in vals],
+                     "steps": steps, "proof_latency_ms_single_in_flight": round(lat, 3),
+                     "circuit": "Poseidon-shaped Merkle inclusion (seeded constants, NOT circomlib-compatible), "
+                                f"{r1cs.depth} levels, {r1cs.nConstraints} constraints, domain 2^{args.log2n}",
+                     "nvars": zk.header.nvars, "ncoeffs": info["ncoeffs"],
+                     "ncoeffs_per_domain_row": round(info["ncoeffs"] / zk.header.domainSize, 3),
+                     "coefficient_dictionary_values": info["dict_values"], "rows_by_terms": info["rows_by_terms"],
+                     "points_at_infinity": {k: inf[k] for k in ("A1", "B1", "B2", "C1", "H1")},
+                     "abc_spmv_ms_standalone": round(rep["abc_spmv"]["total_ms"] / rep["abc_spmv"]["calls"], 4),
+                     "abc_cz_ms_standalone": round(rep["abc_cz"]["total_ms"] / rep["abc_cz"]["calls"], 4)}}
 
 
 def static_inputs(args, shard, dom):
@@ -480,6 +577,13 @@ def finish_rank0(args, world, st):
             raise SystemExit(f"FAIL (witness {k}): {e}")
     log(f"[bench] correctness gate passed for {NWITNESS} distinct witnesses: GPU proof == CPU oracle proof "
         f"(bit-exact), pairing check ok (oracle and GPU verifier)")
+    pos = st.get("poseidon")
+    if pos is not None:
+        try:
+            check_gpu_proof(orc, pos["zkey"], pos["wit"], F.frSeqToMontBytes(pos["wit"]), mask.r, mask.s, pos["proof"], ctx)
+        except AssertionError as e:
+            raise SystemExit(f"FAIL (Poseidon-shaped circuit): {e}")
+        log("[bench] Poseidon-shaped circuit: GPU proof == CPU oracle proof (bit-exact), pairing check ok")
     cpu = None
     if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
         mean_s = sum(cpu_s) / len(cpu_s)
@@ -517,6 +621,9 @@ def finish_rank0(args, world, st):
     extra["proofs_in_flight_per_gpu"] = inflight
     extra["keys_resident_per_gpu"] = 1
     extra["kernels_sha16"] = lib_sha16()
+    if pos is not None:
+        extra["value_poseidon_shape"] = pos["line"]["value"]
+        extra["poseidon_shape"] = pos["line"]
     out.update(extra)
     print(json.dumps(out), flush=True)
 
@@ -529,6 +636,11 @@ def dry_run(args, rank, world):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        injected_failure(args, rank, None)
+    except BaseException as e:       # noqa: BLE001
+        fail_fast(e, rank, world)
+    if world > 1:
         dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     if world > 1:

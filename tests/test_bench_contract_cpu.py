@@ -70,8 +70,27 @@ def test_bench_source_emits_the_same_keys():
     for k in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
               '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"',
               '"frac"', '"cores"', '"kind"', '"sample"', '"roofline_valu"', '"frac_mix"', '"frac_multiply_only"',
-              '"roofline_gather"', '"value_runs"', '"accum_ms_per_proof"', '"overlap_efficiency"'):
+              '"roofline_gather"', '"value_runs"', '"accum_ms_per_proof"', '"overlap_efficiency"',
+              '"value_poseidon_shape"', '"poseidon_shape"'):
         assert k in src, k
+
+
+def test_overlap_efficiency_is_per_gpu_for_any_world_size():
+    """in replica mode EVERY rank proves `steps` proofs in the timed region, so a GPU's time per proof is
+    region / steps whatever the world size -- the value must not shrink by the number of GPUs"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    region_s, steps, acc_ms = 2.4, 288, 6.5
+    one = bench.overlap_efficiency(acc_ms, region_s, steps)
+    assert abs(one - acc_ms / (region_s / steps * 1e3)) < 1e-4 and 0.7 < one < 0.8
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def overlap_efficiency"):src.index("def poseidon_shape")]
+    assert "world" not in body.split('"""')[2]                    # the formula has no world factor
+    # an 8-GPU replica line: value = 8 x per-GPU rate, ms_per_step = region / steps, same efficiency as one GPU
+    value8, ms_per_step8 = 8 * steps / region_s, region_s / steps * 1e3
+    assert abs(bench.overlap_efficiency(acc_ms, region_s, steps) - acc_ms / ms_per_step8) < 1e-4
+    assert abs(value8 - 8e3 / ms_per_step8) < 1e-6
 
 
 def test_accumulate_hot_loops_keep_their_instruction_budget():

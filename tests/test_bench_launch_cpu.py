@@ -61,3 +61,27 @@ def test_single_rank_dry_run_needs_no_launcher():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_ends_the_launch_with_FAIL_and_a_nonzero_code_not_a_signal_or_a_hang():
+    """rank 1 fails before its first collective while rank 0 already waits in the barrier.  The
+    failing rank must say FAIL and leave with a non-zero code at once (no collective to share the failure: the other
+    rank is in a different one), the launcher then ends rank 0; nothing aborts, nothing hangs."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo",
+                        "--inject-failure", "1"], env=_env(), capture_output=True, text=True, timeout=250)
+    dt = time.time() - t0
+    assert r.returncode != 0, (r.stdout, r.stderr[-2000:])
+    assert "FAIL: RuntimeError('injected failure on rank 1')  [rank 1 of 2]" in r.stderr, r.stderr
+    assert "Signal 6" not in r.stderr and "SIGABRT" not in r.stderr and "SIGSEGV" not in r.stderr, r.stderr
+    assert "exitcode  : 1" in r.stderr                       # the launcher's summary: an exit code, not a signal
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no bench line from a failed run
+    assert dt < 120, dt
+
+
+def test_single_rank_failure_is_a_plain_nonzero_exit():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--inject-failure", "0"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "FAIL: RuntimeError('injected failure on rank 0')" in r.stderr

@@ -15,11 +15,22 @@ KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
-def _run(*flags):
+def _sub(*flags, timeout=900):
+    """runs bench.py; the FULL stderr of every run is kept in gpurun_out/ (r04 lost the cause of an abort to a
+    3000-character tail)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True,
-                       text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+                       text=True, timeout=timeout)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    tag = "_".join(f.strip("-") for f in flags)[:80]
+    with open(os.path.join(ROOT, "gpurun_out", f"test_gpu_bench_{tag}.stderr.txt"), "w") as f:
+        f.write(f"exit code {r.returncode}\n---- stdout\n{r.stdout}\n---- stderr\n{r.stderr}")
+    return r
+
+
+def _run(*flags):
+    r = _sub(*flags)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-6000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     assert "correctness gate passed for 3 distinct witnesses" in r.stderr
@@ -64,3 +75,20 @@ def test_bench_two_ranks_replica_mode_from_a_bare_shell():
     d = _run("--gpus", "2", "--backend", "gloo", "--log2n", "13", "--steps", "6", "--warmup", "3", "--inflight", "2")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["mode"] == "replica"
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]     # whole-job aggregate over both ranks
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("mode", ["shard", "replica"])
+def test_bench_rank_failure_is_FAIL_and_exit_code_not_abort_or_hang(mode):
+    """VERDICT r04 weak #6, on the GPU: rank 1 fails after two proofs while rank 0 is inside the next proof's collectives
+    (shard) or its own proofs (replica).  Rounds 3-4 then entered an all-reduce that nobody matched and waited forever
+    (profiles/r05_failpath_old_one_rank_fails_hangs.err.txt); now: FAIL on stderr, exit code != 0, no signal, soon."""
+    import time
+    t0 = time.time()
+    r = _sub("--gpus", "2", "--mode", mode, "--backend", "gloo", "--log2n", "13", "--steps", "6", "--warmup", "3",
+             "--inject-failure", "1:2", timeout=300)
+    assert r.returncode != 0
+    assert "injected failure on rank 1" in r.stderr and "FAIL" in r.stderr and "[rank 1 of 2]" in r.stderr
+    assert "Signal 6" not in r.stderr and "SIGABRT" not in r.stderr and "SIGSEGV" not in r.stderr, r.stderr[-4000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 200
