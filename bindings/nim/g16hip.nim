@@ -111,6 +111,58 @@ proc generateProofWithMask*(nthreads: int, printTimings: bool, zkey: ZKey, wtns:
   result = Proof(curve: "bn128", publicIO: wtns.values[0..zkey.header.npubs])        # prover.nim:238-240
   copyMem(addr result.pi_a, addr p.pi_a, 64); copyMem(addr result.pi_b, addr p.pi_b, 128); copyMem(addr result.pi_c, addr p.pi_c, 64)
 
+# --- one proof over several GPUs of the node: the device group (include/g16hip.h "device group") ------------------------
+# The reference shards every MSM over Taskpool threads (msm.nim:96-122) and runs the three coset pipelines as three tasks
+# (prover.nim:165-173); a group does the same over GPUs, one host thread per device INSIDE the library.  The Nim host only
+# names the devices:   initG16Hip([0, 1, 2, 3, 4, 5, 6, 7]);  loadKeyGpu(zkey);  generateProofWithMask(...)
+type
+  G16Group    {.importc: "g16_group",      header: "g16hip.h", incompleteStruct.} = object
+  G16GroupKey {.importc: "g16_group_pkey", header: "g16hip.h", incompleteStruct.} = object
+proc g16_group_create(devices: ptr int32, ndev: int32, grp: ptr ptr G16Group): int32 {.importc, header: "g16hip.h".}
+proc g16_group_last_error(grp: ptr G16Group): cstring {.importc, header: "g16hip.h".}
+proc g16_group_pkey_create(grp: ptr G16Group, desc: ptr G16PKeyDesc, key: ptr ptr G16GroupKey): int32 {.importc, header: "g16hip.h".}
+proc g16_group_prove(grp: ptr G16Group, key: ptr G16GroupKey, witness: pointer, flags: uint32, r, s: pointer,
+                     res: ptr G16Proof): int32 {.importc, header: "g16hip.h".}
+
+var ggroup: ptr G16Group
+var ggroupKey: ptr G16GroupKey
+
+proc checkGroup(rc: int32) =
+  if rc != 0: raise newException(AssertionDefect, "g16hip group: " & $g16_group_last_error(ggroup))
+
+proc initG16Hip*(devices: openArray[int]) =
+  ## several GPUs: MSMs, NTTs and the verifier of single calls run on devices[0]; proofs are sharded over all of them
+  initG16Hip(devices[0])
+  var ds = newSeq[int32](devices.len)
+  for i, d in devices: ds[i] = int32(d)
+  if g16_group_create(addr ds[0], int32(ds.len), addr ggroup) != 0:
+    raise newException(AssertionDefect, "g16hip: g16_group_create failed")
+
+proc loadKeyGroup*(zkey: ZKey) =
+  ## like loadKeyGpu, sharded: member g keeps index range g of every ProverPoints array (msm.nim:105-115)
+  var cs = newSeq[G16Coeff](zkey.coeffs.len)
+  for i, c in zkey.coeffs:
+    cs[i] = G16Coeff(matrix: uint32(ord(c.matrix)), row: uint32(c.row), col: uint32(c.col))
+    copyMem(addr cs[i].value, unsafeAddr c.coeff, 32)
+  var d = G16PKeyDesc(nvars: uint32(zkey.header.nvars), npubs: uint32(zkey.header.npubs),
+    log2_domain: uint32(zkey.header.logDomainSize), flavour: uint32(ord(zkey.header.flavour)),
+    pointsA1: unsafeAddr zkey.pPoints.pointsA1[0], pointsB1: unsafeAddr zkey.pPoints.pointsB1[0],
+    pointsB2: unsafeAddr zkey.pPoints.pointsB2[0], pointsC1: unsafeAddr zkey.pPoints.pointsC1[0],
+    pointsH1: unsafeAddr zkey.pPoints.pointsH1[0], coeffs: addr cs[0], ncoeffs: csize_t(cs.len),
+    alpha1: unsafeAddr zkey.specPoints.alpha1, beta1: unsafeAddr zkey.specPoints.beta1,
+    delta1: unsafeAddr zkey.specPoints.delta1, beta2: unsafeAddr zkey.specPoints.beta2,
+    delta2: unsafeAddr zkey.specPoints.delta2, shard_index: 0, shard_count: 1)
+  checkGroup g16_group_pkey_create(ggroup, addr d, addr ggroupKey)
+
+proc generateProofWithMaskGroup*(nthreads: int, printTimings: bool, zkey: ZKey, wtns: Witness, mask: Mask): Proof =
+  ## generateProofWithMask (prover.nim:215-304) over the device group: bit-identical to the one-GPU proof
+  assert zkey.header.curve == wtns.curve and zkey.header.nvars == wtns.values.len   # prover.nim:224,236
+  var p: G16Proof
+  checkGroup g16_group_prove(ggroup, ggroupKey, unsafeAddr wtns.values[0], G16_SCALARS_MONT, unsafeAddr mask.r,
+                             unsafeAddr mask.s, addr p)
+  result = Proof(curve: "bn128", publicIO: wtns.values[0..zkey.header.npubs])        # prover.nim:238-240
+  copyMem(addr result.pi_a, addr p.pi_a, 64); copyMem(addr result.pi_b, addr p.pi_b, 128); copyMem(addr result.pi_c, addr p.pi_c, 64)
+
 # continues groth16/gpu/g16hip.nim above: same `header:` style, every type it names is declared here
 type
   G16VKey {.importc: "g16_vkey", header: "g16hip.h", incompleteStruct.} = object

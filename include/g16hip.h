@@ -61,6 +61,10 @@ const char* g16_last_error(const g16_ctx* ctx);
 /* run all work of this context on an existing HIP stream (e.g. torch's current stream); NULL = own stream */
 int32_t g16_ctx_set_stream(g16_ctx* ctx, void* hip_stream);
 int32_t g16_ctx_synchronize(g16_ctx* ctx);
+/* waits for EVERYTHING the context has queued (its main stream and its MSM lanes) and forgets a pending
+ * g16_prove_partials_begin (a later _end returns G16_EINVAL): what a caller does when its exchange between _begin and
+ * _end failed, before it reuses or frees the buffers it handed in */
+int32_t g16_ctx_cancel(g16_ctx* ctx);
 /* layout / constant / arithmetic self-check on the device (sizeof, Montgomery one == frMontR io.nim:91,
  * gen1 on curve, small known-answer MSM and NTT).  The Nim shim calls it once at start-up. */
 int32_t g16_selftest(g16_ctx* ctx);
@@ -244,6 +248,30 @@ int32_t g16_pkey_abc_info(const g16_pkey* key, size_t out[11]);
  * row = wire, col = constraint, x = the Lagrange values.  Host pointers; x: ncols elements, y: nrows elements. */
 int32_t g16_spmv_fr(g16_ctx* ctx, const uint32_t* row, const uint32_t* col, const void* val, size_t nnz, const void* x,
                     size_t ncols, size_t nrows, void* y);
+
+/* ---- device group: one proof over several GPUs from ONE host process -------------------------------------------------
+ * The reference is one process whose MSMs run as Taskpool tasks over contiguous index ranges, partial sums added in task
+ * order (groth16/bn128/msm.nim:96-122), and whose three coset pipelines are three tasks (prover.nim:165-173).  A group is
+ * that shape with GPUs in place of threads: member g = a context on devices[g] + shard g of ndev of the key, one host
+ * thread per member INSIDE the library; per proof the members exchange 3 x 32 n / ndev bytes of coset slices (peer copies
+ * between their HBMs) and member 0 adds the ndev 768-byte records in member order.  The caller needs no Python, no
+ * torch.distributed and no RCCL; it calls g16_group_prove where it called generateProofWithMask.
+ *   devices: HIP device ordinals, one per member (a device may repeat: several members then share it)
+ *   g16_group_pkey_create: desc = the WHOLE key (shard_count 0 or 1); member g keeps index range g of every point set
+ *   g16_group_prove: witness = nvars Fr in HOST memory (flags: G16_SCALARS_MONT or G16_SCALARS_STD), masks as g16_prove;
+ *       the proof is bit-identical to g16_prove's on the unsharded key
+ * A group is used by one host thread at a time.  (Python ranks over RCCL: nim_groth16_amd/distributed.py does the same
+ * exchange with one process per GPU.) */
+typedef struct g16_group g16_group;
+typedef struct g16_group_pkey g16_group_pkey;
+int32_t g16_group_create(const int32_t* devices, int32_t ndev, g16_group** out);
+void g16_group_destroy(g16_group* group);
+int32_t g16_group_size(const g16_group* group);
+const char* g16_group_last_error(const g16_group* group);
+int32_t g16_group_pkey_create(g16_group* group, const g16_pkey_desc* desc, g16_group_pkey** out);
+void g16_group_pkey_destroy(g16_group_pkey* key);
+int32_t g16_group_prove(g16_group* group, const g16_group_pkey* key, const void* witness, uint32_t flags,
+                        const void* mask_r, const void* mask_s, g16_proof* out);
 
 /* ---- verifier ------------------------------------------------------------------------
  * Replaces verifyProof (groth16/verifier.nim:31-52), extractVKey / VKey (groth16/zkey_types.nim:62-73) and the

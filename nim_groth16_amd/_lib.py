@@ -24,6 +24,8 @@ SYMBOLS = [
     "g16_prove_partials_begin", "g16_prove_partials_end",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report", "g16_profile_clock",
     "g16_vkey_create", "g16_vkey_destroy", "g16_verify", "g16_pairing",
+    "g16_ctx_cancel", "g16_group_create", "g16_group_destroy", "g16_group_size", "g16_group_last_error",
+    "g16_group_pkey_create", "g16_group_pkey_destroy", "g16_group_prove",
 ]
 VERIFY_SUBGROUP = 16
 GT_BYTES = 384
@@ -155,6 +157,17 @@ def load_library():
     lib.g16_vkey_destroy.restype = None
     lib.g16_verify.argtypes = [vp, vp, vp, vp, u32, sz, ctypes.POINTER(i32)]
     lib.g16_pairing.argtypes = [vp, vp, vp, sz, vp]
+    lib.g16_ctx_cancel.argtypes = [vp]
+    lib.g16_group_create.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(vp)]
+    lib.g16_group_destroy.argtypes = [vp]
+    lib.g16_group_destroy.restype = None
+    lib.g16_group_size.argtypes = [vp]
+    lib.g16_group_last_error.argtypes = [vp]
+    lib.g16_group_last_error.restype = ctypes.c_char_p
+    lib.g16_group_pkey_create.argtypes = [vp, ctypes.POINTER(PkeyDesc), ctypes.POINTER(vp)]
+    lib.g16_group_pkey_destroy.argtypes = [vp]
+    lib.g16_group_pkey_destroy.restype = None
+    lib.g16_group_prove.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     lib.g16_profile_enable.argtypes = [vp, i32]
     lib.g16_profile_reset.argtypes = [vp]
     lib.g16_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
@@ -162,7 +175,8 @@ def load_library():
     for name in SYMBOLS:
         if name not in ("g16_ctx_destroy", "g16_last_error", "g16_points_release", "g16_points_count",
                         "g16_points_inf_count",
-                        "g16_pkey_destroy", "g16_vkey_destroy"):
+                        "g16_pkey_destroy", "g16_vkey_destroy", "g16_group_destroy", "g16_group_last_error",
+                        "g16_group_pkey_destroy"):
             getattr(lib, name).restype = i32
     _lib = lib
     return lib
@@ -221,6 +235,10 @@ class Context:
 
     def synchronize(self):
         self._check(self._lib.g16_ctx_synchronize(self._h))
+
+    def cancel(self):
+        """drain the main stream and every MSM lane, forget a pending prove_partials_begin (g16_ctx_cancel)"""
+        self._check(self._lib.g16_ctx_cancel(self._h))
 
     # ---- MSM -----------------------------------------------------------------------------------
     def msm(self, group: int, scalars, points, n: int, mont: bool = True, device: bool = False,
@@ -454,6 +472,70 @@ class ProvingKey:
     def __del__(self):
         try:
             self._free()
+        except Exception:
+            pass
+
+
+class DeviceGroup:
+    """g16_group: one proof sharded over several GPUs from ONE process, one host thread per device inside the library
+    (the reference's Taskpool shape, msm.nim:96-122).  devices: HIP ordinals, one per member (repeats allowed)."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        arr = (ctypes.c_int32 * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self._lib.g16_group_create(arr, len(devices), ctypes.byref(h))
+        if rc != G16_OK:
+            raise G16Error(rc, "g16_group_create failed")
+        self._h, self.devices = h, list(devices)
+
+    def _check(self, rc):
+        if rc != G16_OK:
+            raise G16Error(rc, self._lib.g16_group_last_error(self._h).decode())
+
+    def size(self) -> int:
+        return self._lib.g16_group_size(self._h)
+
+    def load_key(self, desc: PkeyDesc, keepalive=None) -> "GroupKey":
+        h = ctypes.c_void_p()
+        self._check(self._lib.g16_group_pkey_create(self._h, ctypes.byref(desc), ctypes.byref(h)))
+        return GroupKey(self, h, desc.nvars)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.g16_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupKey:
+    def __init__(self, group: DeviceGroup, handle, nvars: int):
+        self.group, self._h, self.nvars = group, handle, nvars
+
+    def prove(self, witness: bytes, mont: bool = True, r: bytes = None, s: bytes = None):
+        """-> (pi_a, pi_b, pi_c): g16_group_prove, bit-identical to ProvingKey.prove on the unsharded key"""
+        if len(witness) != 32 * self.nvars:
+            raise ValueError(f"wrong witness length: {len(witness)} bytes, expected {32 * self.nvars}")
+        out = ctypes.create_string_buffer(256)
+        g = self.group
+        g._check(g._lib.g16_group_prove(g._h, self._h, _buf(witness), SCALARS_MONT if mont else 0,
+                                        _buf(r) if r else None, _buf(s) if s else None, out))
+        raw = out.raw
+        return raw[0:64], raw[64:192], raw[192:256]
+
+    def destroy(self):
+        if self._h:
+            self.group._lib.g16_group_pkey_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
         except Exception:
             pass
 

@@ -43,6 +43,8 @@ struct G16Env {
   int tail_quad = 1;              // G16_TAIL_QUAD=0: reduce2 / fold with one lane per slot instead of a cooperating quad (msm.cuh,
                                   // msm_stage.cuh)
   int red_chunk = 0;              // G16_RED_CHUNK = 2 | 4 | 8 | 16: buckets per thread of msm_reduce1 (unset: msm_red_chunk)
+  int cu_split = 0;               // G16_CU_SPLIT=k (1..24): main stream on k CUs per XCD, MSM lanes on the other 32 - k (g16hip.hip)
+  int heavy_grid = 0;             // G16_HEAVY_GRID: workgroups of msm_heavy (unset: 1024 / 512; msm_stage.cuh)
   int abc_dict = 1;               // G16_ABC_DICT=0: buildABC reads a 32-byte value per entry even when the key's coefficients
                                   // come from a small set (spmv.hip: value dictionary)
   int g2_first = -1;              // G16_G2_FIRST = 0 | 1 | 2: A1 and B1 (2: C1 too) accumulate after B2 (unset: 1 for small shards,

@@ -18,6 +18,8 @@ static G16Env read_env() {
   e.table_window = num("G16_TABLE_WINDOW", 5, 22);
   e.msm_seg = num("G16_MSM_SEG", 8, 4096);
   e.red_slice_log2 = num("G16_RED_SLICE", 8, 11);
+  e.cu_split = num("G16_CU_SPLIT", 1, 24);
+  e.heavy_grid = num("G16_HEAVY_GRID", 1, 4096);
   if (const char* v = getenv("G16_INF_COMPACT")) e.inf_compact_pct = atoi(v) < 0 ? 0 : atoi(v) > 101 ? 101 : atoi(v);
   if (const char* v = getenv("G16_R2_WIDTH")) e.r2_width = v[0] == '0' ? 0 : v[0] == '2' ? 2 : 1;
   if (const char* v = getenv("G16_LANES_AFTER_QUOTIENT")) e.lanes_after_quotient = v[0] != '0';
@@ -44,6 +46,22 @@ const G16Env& g16_env() {
   return env;
 }
 
+// ---- CU partition (experiment, G16_CU_SPLIT=k) -----------------------------------------------------
+// With k > 0 the context's main stream (witness upload, buildABC, NTTs, sorts, the fold of H) is created over k CUs of
+// every XCD and the five MSM lanes over the remaining 32 - k: the front of a proof then owns CUs instead of waiting for
+// accumulate waves of other streams to drain.  CU-mask bit i is CU (i / 8) of XCD (i % 8) on this part (the mask is dealt
+// round robin over the XCCs).  Such streams have no priority.  Measured: profiles/r05_ab_cu_split.txt.
+static hipError_t stream_create(hipStream_t* st, int prio_index, bool front) {
+  const int k = g16_env().cu_split;
+  if (k <= 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, g16_stream_priority(prio_index));
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int bit = 0; bit < 256; ++bit) {
+    const bool in_front = bit / 8 < k;
+    if (in_front == front) mask[bit / 32] |= 1u << (bit % 32);
+  }
+  return hipExtStreamCreateWithCUMask(st, 8, mask);
+}
+
 // ---- context ------------------------------------------------------------------------------------
 extern "C" int32_t g16_ctx_create(int32_t device, g16_ctx** out) {
   if (!out) return G16_EINVAL;
@@ -56,7 +74,7 @@ extern "C" int32_t g16_ctx_create(int32_t device, g16_ctx** out) {
   g16_ctx* ctx = new (std::nothrow) g16_ctx();
   if (!ctx) return G16_ENOMEM;
   ctx->device = device;
-  if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, g16_stream_priority(5)) != hipSuccess) {
+  if (stream_create(&ctx->stream, 5, true) != hipSuccess) {
     delete ctx;
     return G16_ENODEV;
   }
@@ -88,8 +106,7 @@ int g16_stream_priority(int index) {
 int32_t g16_lanes_init(g16_ctx* ctx) {
   for (int i = 0; i < 5; ++i) {
     auto& l = ctx->lane[i];
-    if (hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, g16_stream_priority(i)) != hipSuccess)
-      return G16_EHIP;
+    if (stream_create(&l.stream, i, false) != hipSuccess) return G16_EHIP;
     if (hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
   }
   if (hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming) != hipSuccess) return G16_EHIP;
@@ -149,6 +166,16 @@ extern "C" int32_t g16_ctx_set_stream(g16_ctx* ctx, void* hip_stream) {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
   }
+  return G16_OK;
+}
+
+// waits for everything the context has queued (main stream and lanes) and forgets a pending
+// g16_prove_partials_begin: what a caller does after a failed exchange
+extern "C" int32_t g16_ctx_cancel(g16_ctx* ctx) {
+  if (!ctx) return G16_EINVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx_quiesce(ctx);
+  ctx->shard_begun = nullptr;
   return G16_OK;
 }
 
@@ -288,6 +315,10 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
   h->nwin = 254 / h->c + 1;
   h->mtab = g16_pick_mtab(h->c);
   const size_t psz = group == 1 ? 64 : 128;
+  // Two multiplier tables per window double the set's HBM footprint (~10 GB for a 2^20 key, ~40 GB at 2^22): a set
+  // that does not fit that way -- table indices beyond 31 bits, or no room in HBM -- falls back to one table per window
+  // and the plain bucket set (the rounds 1-3 layout) instead of failing.
+  if ((size_t)h->mtab * h->nwin * n >= (size_t(1) << 31)) h->mtab = 1;
   if ((size_t)h->mtab * h->nwin * n >= (size_t(1) << 31)) {
     delete h;
     ctx->err = "point set too large for 31-bit table indices";
@@ -295,6 +326,11 @@ static int32_t points_register(g16_ctx* ctx, int group, const void* points, size
   }
   if (n) {
     hipError_t e = hipMalloc(&h->d_tables, (size_t)h->mtab * h->nwin * n * psz);   // packed reduced-radix entries: 64 / 128 B
+    if (e != hipSuccess && h->mtab == 2) {
+      (void)hipGetLastError();
+      h->mtab = 1;
+      e = hipMalloc(&h->d_tables, (size_t)h->nwin * n * psz);
+    }
     if (e != hipSuccess) {
       delete h;
       ctx->err = "hipMalloc(tables) failed";

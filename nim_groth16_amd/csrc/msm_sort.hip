@@ -39,7 +39,7 @@ static int32_t msm_batch(g16_ctx* ctx, hipStream_t st, const g16_msm_run* runs, 
     const g16_ctx::MsmSort& S = *runs[j].sort;
     const MsmParams& Q = S.P;
     if (Q.n != P.n || Q.c != P.c || Q.nwin != P.nwin || Q.nbuckets != P.nbuckets || Q.seg != P.seg ||
-        Q.tables != P.tables || Q.max_extra != P.max_extra) {
+        Q.tables != P.tables || Q.mtab != P.mtab || Q.max_extra != P.max_extra) {
       ctx->err = "MSM batch: the jobs do not share their launch parameters";
       return G16_EINVAL;
     }

@@ -27,7 +27,8 @@ static int32_t stage_heavy(g16_ctx* ctx, hipStream_t st, const MsmParams& P, con
   // measured in round 2 (profiles/r02_ab_heavy_grid.txt): no change in proofs/s or latency -- the in-order reduce
   // behind it waits for the same slots -- and 30 % slower MSMs for scalars with thousands of split buckets
   // (tools/perf_skew.py "256 values": 3.92 -> 5.11 ms).
-  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, dim3(ny > 1 ? 512 : 1024, ny), heavy_block<C>(),
+  const uint32_t hgrid = g16_env().heavy_grid ? (uint32_t)g16_env().heavy_grid : (ny > 1 ? 512u : 1024u);
+  KLAUNCH_ON(ctx, st, g2 ? "msm_heavy_g2" : "msm_heavy_g1", msm_heavy<C>, dim3(hgrid, ny), heavy_block<C>(),
              heavy_block<C>() * sizeof(typename Ec29<C>::Acc), *(const MsmBatch<C>*)batch, P);
   HIPCHK(ctx, hipGetLastError());
   return G16_OK;

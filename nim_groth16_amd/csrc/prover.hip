@@ -431,8 +431,19 @@ static int32_t launch_h_and_collect(g16_ctx* ctx, const g16_pkey* k, const u256*
     const bool chain = chain_c_into_h(k);
     const g16_msm_run run{&ctx->sort[1], &ctx->lane[4].acc, k->H1->d_tables, nullptr, b.slots + PART_H,
                           chain ? g16_msm_partial_ptr(ctx->lane[3].acc) : nullptr};
-    if (chain) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->ev_c, 0));   // C1's bucket sums are final
-    if ((rc = g16_msm_batch(ctx, M, 1, &run, 1, 1, nullptr))) return rc;
+    // G16_CU_SPLIT: the main stream owns a few CUs per XCD only; the H accumulation then runs on the spare lane (the
+    // large partition), ordered behind the H sort and joined again below
+    hipStream_t HS = g16_env().cu_split ? ctx->lane[4].stream : M;
+    if (HS != M) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev_q, M));
+      HIPCHK(ctx, hipStreamWaitEvent(HS, ctx->ev_q, 0));
+    }
+    if (chain) HIPCHK(ctx, hipStreamWaitEvent(HS, ctx->ev_c, 0));   // C1's bucket sums are final
+    if ((rc = g16_msm_batch(ctx, HS, 1, &run, 1, 1, nullptr))) return rc;
+    if (HS != M) {
+      HIPCHK(ctx, hipEventRecord(ctx->lane[4].done, HS));
+      HIPCHK(ctx, hipStreamWaitEvent(M, ctx->lane[4].done, 0));
+    }
   }
   if (nw)
     for (int i = 0; i < nlanes; ++i) HIPCHK(ctx, hipStreamWaitEvent(M, ctx->lane[i].done, 0));

@@ -18,8 +18,11 @@ BEFORE proof i-1 is finished (H MSM, all-gather, combine), and on an RCCL group 
 final `combine` blocks the host: the library works on a torch stream (g16_ctx_set_stream), the collectives are
 enqueued with async_op=True and ordered against that stream by events (G16_NO_HOST_SYNC).  Every rank issues its
 collectives in the same program order -- scatter x3 (i), all-gather (i-1), scatter x3 (i+1), ... -- which is what
-RCCL requires.  The RCCL transport itself has never run here (one-GPU box): the multi-rank tests rehearse the same
-schedule over gloo, where tensors travel through host memory and the exchange points do block."""
+RCCL requires.  RCCL has carried this schedule's bytes on ONE rank only (round 5: a world-1 `nccl` group with
+`force_collectives`, tests/test_gpu_distributed.py): the API surface -- init with device_id, async scatters with chunk
+lists built under a side stream, async all_gather_into_tensor, stream-ordered waits -- is exercised; xGMI is not, and no
+scaling curve exists.  The multi-rank tests rehearse the same schedule over gloo, where tensors travel through host
+memory and the exchange points do block."""
 from __future__ import annotations
 
 from typing import Callable, Optional
@@ -69,7 +72,8 @@ class ShardedProver:
 
     def __init__(self, zkey, rank: int, world: int, ctx=None, group=None,
                  partials_fn: Optional[Callable] = None, combine_fn: Optional[Callable] = None,
-                 quotient: str = "tasks", pkey=None, depth: int = 2, ctx_factory: Optional[Callable] = None):
+                 quotient: str = "tasks", pkey=None, depth: int = 2, ctx_factory: Optional[Callable] = None,
+                 force_collectives: bool = False):
         import torch.distributed as dist
         self.dist, self.group, self.rank, self.world, self.zkey = dist, group, rank, world, zkey
         self.pkey = pkey                # an already loaded key of this rank's shard, or None: load it here
@@ -80,6 +84,10 @@ class ShardedProver:
         assert quotient in ("tasks", "replicated")
         self.task_quotient = quotient == "tasks" and self.pkey is not None and zkey.header.flavour == 1
         self.depth = max(1, depth)
+        # force_collectives: a group of ONE rank still issues every collective of the schedule -- three async scatters
+        # and one async all-gather per proof, under the slot's stream -- instead of taking the world == 1 shortcuts: the
+        # only way to let RCCL carry this code's bytes on a one-GPU box (tests/test_gpu_distributed.py)
+        self.force = bool(force_collectives)
         self._ctx_factory = ctx_factory     # extra contexts of the pipeline (tests inject CPU stand-ins)
         self._slots = []
         self._head = 0                  # next slot to submit into
@@ -99,7 +107,7 @@ class ShardedProver:
             else:
                 from ._lib import Context
                 s = _Slot(Context(self.pkey.ctx.device), True)
-            if not self.group_is_cpu() and self.world > 1:
+            if not self.group_is_cpu() and (self.world > 1 or self.force):
                 # the library launches on a torch stream, so that collectives enqueued under it are ordered against
                 # the library's work by events instead of host waits
                 dev = torch.device(f"cuda:{self.pkey.ctx.device}")
@@ -130,7 +138,7 @@ class ShardedProver:
         owned = self._owned
         self.pkey.prove_partials_begin(witness, sum(1 << v for v in owned), s.task_out.data_ptr() if owned else None,
                                        mont=mont, device=device, ctx=s.ctx, nosync=s.stream is not None)
-        if world == 1:
+        if world == 1 and not self.force:
             return
         vec = s.task_out.cpu() if (cpu_group and owned) else s.task_out
         with (torch.cuda.stream(s.stream) if s.stream is not None else _null()):
@@ -162,7 +170,7 @@ class ShardedProver:
         nh = self._ranges[rank][1] - self._ranges[rank][0]
         with (torch.cuda.stream(s.stream) if s.stream is not None else _null()):
             if self.task_quotient:
-                if world == 1:
+                if world == 1 and not self.force:
                     ptrs = [s.task_out.data_ptr() + 32 * n * v for v in range(3)]
                 else:
                     for w in s.works:
@@ -175,7 +183,7 @@ class ShardedProver:
                                              nosync=s.stream is not None)
             mine = s.mine.cpu() if cpu_group else s.mine
             gathered = torch.empty(world * PARTIALS_BYTES, dtype=torch.uint8) if cpu_group else s.gathered
-            if world > 1:
+            if world > 1 or self.force:
                 work = self.dist.all_gather_into_tensor(gathered, mine, group=self.group,   # 768 bytes per rank per proof
                                                         async_op=not cpu_group)
                 if not cpu_group:
@@ -206,14 +214,15 @@ class ShardedProver:
                 self.pkey.prove_partials(witness, mont=mont, device=device, out=slot.mine.data_ptr(), ctx=slot.ctx)
         except BaseException:
             # A failed begin / exchange may leave the witness lanes of `begin` running and a proof pending on the
-            # context.  g16_ctx_synchronize would wait for the main stream only and keep the pending proof; a call that
-            # enters the context the ordinary way drains EVERY lane and cancels it (include/g16hip.h) -- the self-test
-            # is the cheapest one.  The slot stays free: `_head` has not moved.
+            # context: g16_ctx_cancel drains the main stream AND every lane and forgets the pending proof (a plain
+            # synchronize would wait for the main stream only).  The slot stays free: `_head` has not moved.  The
+            # original exception is the one the caller sees, whatever the cancel does.
             slot.job, slot.works = None, []
             try:
-                slot.ctx.selftest()
-            finally:
-                raise
+                slot.ctx.cancel()
+            except Exception:           # noqa: BLE001
+                pass
+            raise
         self._head = (self._head + 1) % self.depth
         self._inflight.append(slot)
         return done
@@ -272,7 +281,7 @@ class ShardedProver:
 
     def group_is_cpu(self) -> bool:
         """True when the process group cannot move CUDA tensors (backend gloo)"""
-        if self.world <= 1 or not self.dist.is_initialized():
+        if (self.world <= 1 and not self.force) or not self.dist.is_initialized():
             return False
         return "nccl" not in str(self.dist.get_backend(self.group)).lower()
 

@@ -60,6 +60,22 @@ def loadProvingKey(zkey: ZKey, ctx=None, shard_index: int = 0, shard_count: int 
     return ProvingKey(ctx, desc, bufs)
 
 
+def loadGroupKey(zkey: ZKey, group):
+    """The ZKey sharded over the members of a _lib.DeviceGroup (g16_group_pkey_create): member g keeps index range g of
+    every ProverPoints array (msm.nim:105-115)."""
+    hdr, pts, spec = zkey.header, zkey.pPoints, zkey.specPoints
+    assert len(pts.pointsA1) == 64 * hdr.nvars and len(pts.pointsB1) == 64 * hdr.nvars
+    assert len(pts.pointsB2) == 128 * hdr.nvars and len(pts.pointsH1) == 64 * hdr.domainSize
+    assert len(pts.pointsC1) == 64 * (hdr.nvars - hdr.npubs - 1)
+    bufs = [_cbuf(x) for x in (pts.pointsA1, pts.pointsB1, pts.pointsB2, pts.pointsC1, pts.pointsH1,
+                               packCoeffs(zkey.coeffs), spec.alpha1, spec.beta1, spec.delta1, spec.beta2,
+                               spec.delta2)]
+    addr = [ctypes.cast(b, ctypes.c_void_p) for b in bufs]
+    desc = PkeyDesc(hdr.nvars, hdr.npubs, hdr.logDomainSize, hdr.flavour, addr[0], addr[1], addr[2], addr[3],
+                    addr[4], addr[5], len(zkey.coeffs), addr[6], addr[7], addr[8], addr[9], addr[10], 0, 1)
+    return group.load_key(desc, bufs)
+
+
 _pkey_cache = {}
 
 

@@ -84,6 +84,16 @@ def test_config4_2p22_sharded_over_8_ranks_by_hand(ctx, orc):
         for c in ranks:
             c.close()
     assert sharded == whole, "the proof combined from 8 shard records differs from the unsharded proof"
+    # the same configuration through the C-ABI device group (g16_group_*: eight members, one host thread each inside the
+    # library, slices moved by device copies) -- what a Nim host calls instead of driving the ranks itself
+    from nim_groth16_amd import DeviceGroup, loadGroupKey
+    grp = DeviceGroup([0] * G)
+    gk = loadGroupKey(zk, grp)
+    try:
+        assert gk.prove(wb, r=rb, s=sb) == whole, "g16_group_prove over 8 members differs from the unsharded proof"
+    finally:
+        gk.destroy()
+        grp.close()
     pio = wb[:32 * (zk.header.npubs + 1)]
     assert verifyProof(extractVKey(zk), Proof(pio, *sharded), ctx)
     check_gpu_proof(orc, zk, wit, wb, mask.r, mask.s, sharded, ctx)

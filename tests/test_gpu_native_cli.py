@@ -50,6 +50,12 @@ def test_native_cli_matches_python_host(ctx, tmp_path, circuit):
     assert "verification succeeded" in out.stdout
     assert open(tmp_path / "proof.json").read() == open(tmp_path / "py_proof.json").read()
     assert open(tmp_path / "public.json").read() == open(tmp_path / "py_public.json").read()
+    # the proof sharded over a device group (three members, all on this box's one GPU): the same bytes
+    out = subprocess.run([exe, "-z", zpath, "-w", wpath, "-o", str(tmp_path / "proof_g.json"), "-i",
+                          str(tmp_path / "public_g.json"), "-n", "-y", "--gpus", "0,0,0"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "verification succeeded" in out.stdout, out.stderr
+    assert open(tmp_path / "proof_g.json").read() == open(tmp_path / "py_proof.json").read()
     # a random mask still verifies (on the GPU verifier inside the tool) and gives a different proof
     out = subprocess.run([exe, "-z", zpath, "-w", wpath, "-o", str(tmp_path / "proof2.json"), "-i",
                           str(tmp_path / "public2.json"), "-y"], capture_output=True, text=True, timeout=600)

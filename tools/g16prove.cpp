@@ -4,7 +4,10 @@
 //
 //   g++ -O2 -std=c++17 -Iinclude tools/g16prove.cpp -Lnim_groth16_amd/csrc -lg16hip
 //       -Wl,-rpath,$PWD/nim_groth16_amd/csrc -o g16prove
-//   ./g16prove -z circuit.zkey -w witness.wtns -o proof.json -i public.json [-n] [-y] [-t]
+//   ./g16prove -z circuit.zkey -w witness.wtns -o proof.json -i public.json [-n] [-y] [-t] [--gpus 0,1,2,3]
+//
+// --gpus d0,d1,...: the proof sharded over those devices through the device group of the C ABI (g16_group_*: one host
+// thread per device inside the library; the reference's Taskpool shape, msm.nim:96-122).  A device may repeat.
 //
 // The file readers live in tools/g16_files.hpp.
 #define G16_TOOL_NAME "g16prove"
@@ -13,6 +16,7 @@
 int main(int argc, char** argv) {
   const char *zpath = nullptr, *wpath = nullptr, *opath = "proof.json", *ipath = "public.json";
   bool nomask = false, verify = false, timing = false;
+  std::vector<int32_t> gpus;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() -> const char* {
@@ -26,7 +30,16 @@ int main(int argc, char** argv) {
     else if (a == "-n" || a == "--nomask") nomask = true;   // cli_main.nim -n
     else if (a == "-y" || a == "--verify") verify = true;   // cli_main.nim -y
     else if (a == "-t" || a == "--time") timing = true;     // cli_main.nim -t
-    else die("unknown option " + a + "\nusage: g16prove -z circuit.zkey -w witness.wtns [-o proof.json] [-i public.json] [-n] [-y] [-t]");
+    else if (a == "--gpus") {
+      for (const char* q = next(); *q;) {
+        char* end = nullptr;
+        const long d = strtol(q, &end, 10);
+        if (end == q || d < 0) die("--gpus takes a comma-separated list of device ordinals");
+        gpus.push_back((int32_t)d);
+        q = *end == ',' ? end + 1 : end;
+      }
+    }
+    else die("unknown option " + a + "\nusage: g16prove -z circuit.zkey -w witness.wtns [-o proof.json] [-i public.json] [-n] [-y] [-t] [--gpus 0,1,...]");
   }
   if (!zpath || !wpath) die("usage: g16prove -z circuit.zkey -w witness.wtns [-o proof.json] [-i public.json] [-n] [-y] [-t]");
 
@@ -38,14 +51,22 @@ int main(int argc, char** argv) {
   const double t1 = now();
 
   g16_ctx* ctx = nullptr;
-  if (g16_ctx_create(0, &ctx) != G16_OK) die("no usable GPU (there is no CPU fallback)");
+  if (g16_ctx_create(gpus.empty() ? 0 : gpus[0], &ctx) != G16_OK) die("no usable GPU (there is no CPU fallback)");
   auto chk = [&](int32_t rc, const char* what) {
     if (rc != G16_OK) die(std::string(what) + " failed: " + g16_last_error(ctx));
   };
   chk(g16_selftest(ctx), "g16_selftest");
   g16_pkey_desc d = zf.desc();
   g16_pkey* key = nullptr;
-  chk(g16_pkey_create(ctx, &d, &key), "g16_pkey_create");
+  g16_group* grp = nullptr;
+  g16_group_pkey* gkey = nullptr;
+  if (gpus.empty()) {
+    chk(g16_pkey_create(ctx, &d, &key), "g16_pkey_create");
+  } else {
+    if (g16_group_create(gpus.data(), (int32_t)gpus.size(), &grp) != G16_OK) die("g16_group_create failed");
+    if (g16_group_pkey_create(grp, &d, &gkey) != G16_OK)
+      die(std::string("g16_group_pkey_create failed: ") + g16_group_last_error(grp));
+  }
   const double t2 = now();
 
   // mask (prover.nim:312-319): r, s uniform in Fr unless -n; passed in Montgomery form
@@ -65,7 +86,12 @@ int main(int argc, char** argv) {
     rp = rmask, sp = smask;
   }
   g16_proof proof;
-  chk(g16_prove(ctx, key, wvals, G16_SCALARS_STD, rp, sp, &proof), "g16_prove");
+  if (grp) {
+    if (g16_group_prove(grp, gkey, wvals, G16_SCALARS_STD, rp, sp, &proof) != G16_OK)
+      die(std::string("g16_group_prove failed: ") + g16_group_last_error(grp));
+  } else {
+    chk(g16_prove(ctx, key, wvals, G16_SCALARS_STD, rp, sp, &proof), "g16_prove");
+  }
   const double t3 = now();
 
   FILE* f = fopen(opath, "w");  // export_json.nim:70-80
@@ -99,6 +125,8 @@ int main(int argc, char** argv) {
   if (timing)
     printf("parsing %.3fs | key upload + tables %.3fs | proof %.3fs\n", t1 - t0, t2 - t1, t3 - t2);
   g16_pkey_destroy(key);
+  g16_group_pkey_destroy(gkey);
+  g16_group_destroy(grp);
   g16_ctx_destroy(ctx);
   return 0;
 }
