@@ -63,19 +63,6 @@ struct Fp29Params {
   static constexpr Limbs29 C_OUT = {{0x58f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu,
                                      0x1cbd99bau, 0x183340fbu, 0xe0a77u}};
 };
-// the scalar field r (the NTT butterflies, ntt29.cuh)
-struct Fr29Params {
-  static constexpr uint32_t N0 = 0xfffffffu, PINV0 = 0x10000001u;
-  static constexpr Limbs29 PL = {{0x10000001u, 0x1f0fac9fu, 0xe5c2450u, 0x7d090f3u, 0x1585d283u, 0x2db40c0u,
-                                  0xa6e141u, 0xe5c2634u, 0x30644eu}};
-  static constexpr Limbs29 ONE = {{0xfffff57u, 0x1ea70ab4u, 0x52c068bu, 0x17504f49u, 0xaa8075bu, 0x1d4240ceu,
-                                   0x11d54c07u, 0x52ac7a8u, 0xdc836u}};
-  static constexpr Limbs29 C_IN = {{0xfffead7u, 0x1d5444f4u, 0x4438aa5u, 0x3b4d096u, 0x134c84dau, 0xe92d304u,
-                                    0x14cb95b3u, 0x41b9d3du, 0x58003u}};
-  static constexpr Limbs29 C_OUT = {{0xffffffbu, 0x4b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu, 0x11b7bc3cu,
-                                     0x1cbd99bau, 0x183340fbu, 0xe0a77u}};
-};
-
 template <class PR>
 struct Field29 {
   static constexpr int B = 29, L = 9;
@@ -505,6 +492,5 @@ struct Field29 {
   static FF_HD u256 to_std(const fe29& a) { return relimb(canon<1>(mul(a, constant(C_OUT)))); }
 };
 using Fp29 = Field29<Fp29Params>;
-using Fr29 = Field29<Fr29Params>;
 
 }  // namespace g16

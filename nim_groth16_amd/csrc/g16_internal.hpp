@@ -36,8 +36,6 @@ struct G16Env {
   int lanes_after_quotient = 0;   // G16_LANES_AFTER_QUOTIENT=1 (with the above): the witness accumulations wait for them
   int g1_batch = 0;               // G16_G1_BATCH=1: ONE batched launch sequence (blockIdx.y = MSM) for A1, B1, C1 on one stream
                                   // instead of one stream and one sequence per G1 MSM (prover.hip; measured slower)
-  int ntt_field = 32;             // G16_NTT_FIELD=29: the reduced-radix NTT passes of ntt29.cuh instead of ntt.cuh's 8 x 32 ones
-                                  // (bit-identical; measured: passes -5 %, fused last pass +18 %, proofs/s -1.6 %)
   int mtab = 2;                   // G16_MTAB=1: registered sets without the second multiplier table / class bucket set
   int chain_ch = 1;               // G16_CHAIN_CH=0: C1 and H1 as two MSMs instead of H1 continuing C1's bucket sums
   int tail_quad = 1;              // G16_TAIL_QUAD=0: reduce2 / fold with one lane per slot instead of a cooperating quad (msm.cuh,
@@ -106,7 +104,6 @@ struct g16_ctx {
   Buf ntt_tw;    // twiddle table
   Buf ntt_tmp;   // ping-pong buffers
   Buf coset[2];  // eta^(+-i)/n tables (ntt_make_coset_table)
-  Buf ntt_tw29, ntt_twc, coset29[2];   // the same tables in the 2^261 form of the reduced-radix passes (ntt29.cuh)
   Buf quot;      // 6n work area of the quotient pipeline
   Buf prove;     // per-proof scalars: witness, Az|Bz|Cz, qs
   Buf fb_table[2];  // fixed-base tables of gen1 / gen2

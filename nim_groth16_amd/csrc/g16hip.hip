@@ -31,7 +31,6 @@ static G16Env read_env() {
   if (const char* v = getenv("G16_TAIL_QUAD")) e.tail_quad = v[0] != '0';
   if (const char* v = getenv("G16_G2_FIRST")) e.g2_first = v[0] == '2' ? 2 : v[0] != '0';
   if (const char* v = getenv("G16_MTAB")) e.mtab = v[0] == '1' ? 1 : 2;
-  if (const char* v = getenv("G16_NTT_FIELD")) e.ntt_field = atoi(v) == 29 ? 29 : 32;
   if (const char* v = getenv("G16_NTT_TILE")) e.ntt_tile = atoi(v) == 1024 ? 1024 : atoi(v) == 4096 ? 4096 : 2048;
   if (const char* v = getenv("G16_MSM_SORT")) e.msm_sort = v[0];
   if (const char* v = getenv("G16_G1_LANES"))
@@ -136,8 +135,7 @@ extern "C" void g16_ctx_destroy(g16_ctx* ctx) {
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   if (ctx->ev_g2) (void)hipEventDestroy(ctx->ev_g2);
   for (g16_ctx::Buf* b : {&ctx->stage_s, &ctx->stage_p, &ctx->stage_p29, &ctx->stage_o, &ctx->ntt_tw, &ctx->ntt_tmp,
-                          &ctx->coset[0], &ctx->coset[1], &ctx->ntt_tw29, &ctx->ntt_twc, &ctx->coset29[0],
-                          &ctx->coset29[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
+                          &ctx->coset[0], &ctx->coset[1], &ctx->quot, &ctx->prove, &ctx->fb_table[0],
                           &ctx->fb_table[1]})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->prof) {

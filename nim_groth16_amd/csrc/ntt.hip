@@ -4,7 +4,6 @@
 
 #include "g16_internal.hpp"
 #include "ntt.cuh"
-#include "ntt29.cuh"
 
 using namespace g16;
 
@@ -16,18 +15,6 @@ static int32_t ensure_twiddles(g16_ctx* ctx, uint32_t log2n) {
   if ((rc = ensure(ctx, ctx->ntt_tw, (n / 2 + 1) * 32))) return rc;
   KLAUNCH(ctx, "ntt_twiddles", ntt_make_twiddles, (uint32_t)((n / 2 + 1 + 255) / 256), 256, 0, (u256*)ctx->ntt_tw.p,
           log2n);
-  ctx->tw_log2n = log2n;
-  if (g16_env().ntt_field != 29) return G16_OK;
-  // the reduced-radix passes (ntt29.cuh) read the same powers in the 2^261 form, and the inner-stage twiddles of
-  // both directions from a compact table
-  const uint32_t rmax = log2n < 10 ? log2n : 10, chalf = (1u << rmax) >> 1;
-  if ((rc = ensure(ctx, ctx->ntt_tw29, (n / 2 + 1) * sizeof(fe29)))) return rc;
-  if ((rc = ensure(ctx, ctx->ntt_twc, (size_t)(2 * chalf + 1) * sizeof(fe29)))) return rc;
-  KLAUNCH(ctx, "ntt_twiddles", ntt29_convert_table, (uint32_t)((n / 2 + 1 + 255) / 256), 256, 0,
-          (const u256*)ctx->ntt_tw.p, (fe29*)ctx->ntt_tw29.p, (uint32_t)(n / 2 + 1));
-  if (chalf)
-    KLAUNCH(ctx, "ntt_twiddles", ntt29_compact_twiddles, (2 * chalf + 255) / 256, 256, 0, (const u256*)ctx->ntt_tw.p,
-            (fe29*)ctx->ntt_twc.p, log2n, rmax);
   ctx->tw_log2n = log2n;
   return G16_OK;
 }
@@ -55,11 +42,6 @@ static int32_t ntt_kernels_init(g16_ctx* ctx) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_last_pass_abc<NTT_BLOCK_MID, NTT_TILE_MID>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_shmem));
-  const int shmem29 = (int)(sizeof(fe29) * NTT_TILE_MID);   // 72 KB: the tile alone (inner twiddles come from global memory)
-  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt29_pass<NTT_BLOCK_MID>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, shmem29));
-  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt29_last_pass_abc<NTT_BLOCK_MID, NTT_TILE_MID>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, shmem29));
   done.store(true, std::memory_order_release);
   return G16_OK;
 }
@@ -82,20 +64,6 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
   }
   // passes of <= 10 stages: one up to 2^10, two up to 2^20, three beyond (small geometry: <= 8 stages per pass)
   const bool small = g16_env().ntt_tile == NTT_TILE_SMALL, mid = g16_env().ntt_tile == NTT_TILE_MID;
-  // reduced-radix butterflies (ntt29.cuh): the default geometry only
-  const bool f29 = mid && g16_env().ntt_field == 29;
-  const uint32_t rmax = log2n < 10 ? log2n : 10, chalf = (1u << rmax) >> 1;
-  const fe29* tw29 = (const fe29*)ctx->ntt_tw29.p;
-  const fe29* twc = (const fe29*)ctx->ntt_twc.p + (inverse ? chalf : 0);
-  const fe29* scale29 = nullptr;
-  if (f29 && scale) {
-    for (int m = 0; m < 2; ++m)
-      if (scale == (const u256*)ctx->coset[m].p) scale29 = (const fe29*)ctx->coset29[m].p;
-    if (!scale29) {
-      ctx->err = "ntt: unknown scale table";
-      return G16_EINVAL;
-    }
-  }
   const uint32_t max_rho = small ? NTT_MAX_RHO_SMALL : NTT_MAX_RHO, log2tile = small ? 10 : mid ? 11 : 12;
   const uint32_t npass = log2n ? (log2n + max_rho - 1) / max_rho : 1;
   u256 *tmpA = nullptr, *tmpB = nullptr;
@@ -114,12 +82,6 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
     const bool last = p + 1 == npass;
     const size_t shmem = pass_shmem(rho, log2b);
     const uint32_t ntiles = 1u << (log2n - rho - log2b);
-    if (last && fuse_abc && f29) {
-      KLAUNCH(ctx, "ntt_last_pass_abc", (ntt29_last_pass_abc<NTT_BLOCK_MID, NTT_TILE_MID>), ntiles, NTT_BLOCK_MID,
-              sizeof(fe29) << (rho + log2b), src, out, twc, rmax - rho, log2n, log2s, rho, log2b, src_stride,
-              fuse_abc == 2 ? 1 : 0);
-      break;
-    }
     if (last && fuse_abc) {
       if (small)
         KLAUNCH(ctx, "ntt_last_pass_abc", (ntt_last_pass_abc<NTT_BLOCK_SMALL, NTT_TILE_SMALL>), ntiles, NTT_BLOCK_SMALL,
@@ -134,11 +96,7 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
     }
     u256* dst = last ? out : ((p & 1) ? tmpB : tmpA);
     const size_t dst_stride = last ? out_stride : n;
-    if (f29)
-      KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt29_pass<NTT_BLOCK_MID>, dim3(ntiles, batch),
-              NTT_BLOCK_MID, sizeof(fe29) << (rho + log2b), src, dst, tw29, twc, rmax - rho, log2n, log2s, rho, log2b,
-              inverse, last ? 1 : 0, src_stride, dst_stride, last ? scale29 : (const fe29*)nullptr);
-    else if (small)
+    if (small)
       KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK_SMALL>, dim3(ntiles, batch),
               NTT_BLOCK_SMALL, shmem, src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse,
               last ? 1 : 0, src_stride, dst_stride, last ? scale : (const u256*)nullptr);
@@ -178,10 +136,6 @@ static int32_t ensure_coset(g16_ctx* ctx, uint32_t log2n, int mode) {
   KLAUNCH(ctx, "ntt_coset_table", ntt_make_coset_table, (uint32_t)((n + 255) / 256), 256, 0,
           (u256*)ctx->coset[mode].p, log2n, mode);
   ctx->coset_log2n[mode] = log2n;
-  if (g16_env().ntt_field != 29) return G16_OK;
-  if ((rc = ensure(ctx, ctx->coset29[mode], n * sizeof(fe29)))) return rc;
-  KLAUNCH(ctx, "ntt_coset_table", ntt29_convert_table, (uint32_t)((n + 255) / 256), 256, 0,
-          (const u256*)ctx->coset[mode].p, (fe29*)ctx->coset29[mode].p, (uint32_t)n);
   return G16_OK;
 }
 

@@ -3,7 +3,6 @@
 #include "../../nim_groth16_amd/csrc/ec29.cuh"
 #include "../../nim_groth16_amd/csrc/pairing.cuh"
 #include "../../nim_groth16_amd/csrc/msm_params.hpp"
-#include "../../nim_groth16_amd/csrc/ntt29.cuh"
 #include <cstring>
 #include <vector>
 using namespace g16;
@@ -69,27 +68,6 @@ uint32_t shim_bs_block_check(uint32_t nparts) {
   }
   return 0;
 }
-
-// ntt29.cuh, the radix-4 group of the reduced-radix NTT: x[4] = values (standard integers below V * r, 36 bytes each
-// as nine 29-bit limbs, normalized by the caller), t[3] = twiddles (canonical Montgomery-256 form), out: the four
-// outputs as canonical standard integers (the 2^-261 of the products undone: data stay in whatever form they came)
-void shim_ntt29_group4(const uint32_t* x, const void* tw, uint32_t V, int p_nz, int reduce, uint32_t* out) {
-  fe29 v[4];
-  for (int i = 0; i < 4; ++i)
-    for (int k = 0; k < 9; ++k) v[i].v[k] = x[9 * i + k];
-  fe29 t[3];
-  for (int i = 0; i < 3; ++i) t[i] = Fr29::from_std(ld<u256>((const char*)tw + 32 * i));
-  Ntt29::group4(v[0], v[1], v[2], v[3], p_nz != 0, t[0], t[1], t[2], Ntt29::kmult(V + 1, 1), Ntt29::kmult(2 * V + 1, 2),
-                reduce != 0);
-  for (int i = 0; i < 4; ++i)
-    for (int k = 0; k < 9; ++k) out[9 * i + k] = v[i].v[k];
-}
-void shim_ntt29_store_any(const uint32_t* x, void* out) {
-  fe29 v;
-  for (int k = 0; k < 9; ++k) v.v[k] = x[k];
-  st(out, Ntt29::store_any(v));
-}
-uint32_t shim_ntt29_v_after_group(uint32_t V, int reduce) { return Ntt29::v_after_group(V, reduce != 0); }
 
 // the class bucket set of registered point sets with two multiplier tables (msm_params.hpp): every digit magnitude
 // t in [1, 2^(c-1)] must land in a bucket whose weight (from the class layout, restated here) times 2^s is t, every

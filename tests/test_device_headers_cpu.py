@@ -218,67 +218,6 @@ def test_class_bucket_set_of_two_multiplier_tables(shim):
         assert shim.shim_class_buckets_check(c) == 0, c
 
 
-def test_ntt29_radix4_group_at_its_bounds(shim):
-    """ntt29.cuh: one radix-4 group of the reduced-radix NTT against Python integers, with inputs AT the value bound V r
-    of every round trip a 10-stage (and a 9-stage) pass goes through, maximal limbs included: any 32-bit limb or 64-bit
-    column that overflowed would change a residue.  Also the bound recursion itself and the canonical store."""
-    R = o.R
-    M256 = pow(2, 256, R)
-    rng = random.Random(29)
-    shim.shim_ntt29_v_after_group.restype = ctypes.c_uint32
-
-    def limbs(x):                       # normalized: limbs 0..7 < 2^29, the top limb carries the rest (< 2^32)
-        assert x >> 232 < 1 << 32
-        return [(x >> (29 * i)) & ((1 << 29) - 1) for i in range(8)] + [x >> 232]
-
-    def value(l):
-        return sum(int(v) << (29 * i) for i, v in enumerate(l))
-
-    chains = []
-    for first in (1, 6):                # even rho: V = 1; odd rho: one radix-2 stage first (V = 6)
-        V, trip = first, 0
-        while trip < 5:
-            chains.append((V, trip == 2))
-            V = shim.shim_ntt29_v_after_group(V, 1 if trip == 2 else 0)
-            trip += 1
-        assert V <= 197
-    for V, reduce in chains:
-        for p_nz in (0, 1):
-            for case in range(12):
-                if case == 0:
-                    xs = [V * R - 1] * 4
-                elif case == 1:
-                    xs = [V * R - 1, 0, 0, V * R - 1]
-                elif case == 2:
-                    xs = [0, V * R - 1, V * R - 1, 0]
-                elif case == 3:           # maximal limbs below the bound: all-ones pattern
-                    m = min(V * R - 1, ((V * R - 1) >> 232 << 232) - 1 if V > 1 else R - 1)
-                    xs = [m] * 4
-                else:
-                    xs = [rng.randrange(V * R) for _ in range(4)]
-                tw = [rng.randrange(1, R) if case else R - 1 for _ in range(3)]
-                xin = (ctypes.c_uint32 * 36)(*[v for x in xs for v in limbs(x)])
-                twb = b"".join((t * M256 % R).to_bytes(32, "little") for t in tw)
-                out = (ctypes.c_uint32 * 36)()
-                shim.shim_ntt29_group4(xin, twb, V, p_nz, 1 if reduce else 0, out)
-                got = [value(out[9 * i:9 * i + 9]) for i in range(4)]
-                for i in range(4):          # normalized outputs
-                    assert all(out[9 * i + k] < 1 << 29 for k in range(8))
-                x0, x1, x2, x3 = xs
-                tA2, tA3, tB = tw if p_nz else (1, tw[1], 1)
-                a0, a1, a2, a3 = x0 + x2, x1 + x3, (x0 - x2) * tA2, (x1 - x3) * tA3
-                want = [a0 + a1, (a0 - a1) * tB, a2 + a3, (a2 - a3) * tB]
-                Vn = shim.shim_ntt29_v_after_group(V, 1 if reduce else 0)
-                for g, w in zip(got, want):
-                    assert g % R == w % R, (V, reduce, p_nz, case)
-                    assert g < Vn * R, (V, reduce, p_nz, case, g // R, Vn)
-                # the canonical store of every output
-                for i in range(4):
-                    buf = ctypes.create_string_buffer(32)
-                    shim.shim_ntt29_store_any((ctypes.c_uint32 * 9)(*out[9 * i:9 * i + 9]), buf)
-                    assert int.from_bytes(buf.raw, "little") == want[i] % R
-
-
 def test_sort_block_order_is_a_bijection_and_keeps_a_partition_on_one_xcd(shim):
     """bs_block (msm_params.hpp): the workgroup order of bucket_hist / bucket_place -- every (partition, slice) once;
     with a partition count that is a multiple of 8 all eight slices of a partition share the block index modulo 8 (the

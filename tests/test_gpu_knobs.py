@@ -85,7 +85,6 @@ KNOBS = [
     {"G16_G1_BATCH": "1"},                                      # A1, B1, C1 as one batched launch sequence (round 4)
     {"G16_G1_BATCH": "1", "G16_CHAIN_CH": "0", "G16_INF_COMPACT": "0", "G16_MSM_SEG": "8"},   # ... with own sorts, split buckets
     {"G16_CHAIN_CH": "0"},                                      # C1 and H1 as two separate MSMs (rounds 1-3)
-    {"G16_NTT_FIELD": "29"},                                    # reduced-radix NTT passes (ntt29.cuh; round 4)
     {"G16_MTAB": "1"},                                          # one table per window, plain bucket set (rounds 1-3)
     {"G16_TABLE_WINDOW": "15"},                                 # the smallest window with the class bucket set
     {"G16_TABLE_WINDOW": "17", "G16_MSM_SORT": "a"},           # class bucket set through the global-atomic sort
