@@ -128,8 +128,13 @@ class _FakeCtx:
     def synchronize(self):
         pass
 
+    cancels = 0
+
     def selftest(self):                # an ordinary context entry: drains every lane, cancels a pending begin
         self.selftests += 1
+
+    def cancel(self):                  # g16_ctx_cancel: drains every lane and forgets a pending begin
+        self.cancels += 1
 
     def set_stream(self, ptr):
         pass
@@ -261,8 +266,9 @@ def test_sharded_pipeline_world2_gloo_depth2():
 
 
 def test_failed_begin_leaves_the_pipeline_consistent():
-    """a begin that raises must not consume a slot -- `_head` stays, the slot's context is quiesced through
-    an ordinary entry (which cancels the pending proof), and the proofs submitted before and after come out in order."""
+    """a begin that raises must not consume a slot -- `_head` stays, the slot's context is drained and
+    its pending proof forgotten (g16_ctx_cancel), the ORIGINAL exception reaches the caller, and the proofs submitted
+    before and after come out in order."""
     from nim_groth16_amd.distributed import ShardedProver
     from nim_groth16_amd.zkey_types import GrothHeader, ZKey
     oz, r, s = _setup()
@@ -281,9 +287,9 @@ def test_failed_begin_leaves_the_pipeline_consistent():
     wb = I.fr_mont_bytes(o.TOY_WITNESS)
     rb, sb = o.fr_to_mont_bytes(r), o.fr_to_mont_bytes(s)
     assert sp.submit(wb, True, rb, sb) is None
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="injected begin failure"):
         sp.submit(wb, True, sb, rb)                      # would have gone into slot 1
-    assert sp._head == 1 and len(sp._inflight) == 1 and sp._slots[1].ctx.selftests == 1 and sp._slots[1].job is None
+    assert sp._head == 1 and len(sp._inflight) == 1 and sp._slots[1].ctx.cancels == 1 and sp._slots[1].job is None
     assert sp.submit(wb, True, sb, rb) is None           # the same slot again
     out = sp.collect()
     want = []
