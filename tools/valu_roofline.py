@@ -163,14 +163,18 @@ def main():
     tag = sys.argv[4] if len(sys.argv) > 4 else "r02"          # the -o prefix given to rocprofv3
     tab = ubench_table(ubench_path)
     counters = pmc(pmc_root, tag)
+    for extra in sys.argv[5:]:                                 # further counter passes (e.g. .../valu_abc: buildABC)
+        for k, v in pmc(extra, tag).items():
+            counters.setdefault(k, v)
     csrc = os.path.join(ROOT, "nim_groth16_amd", "csrc")
     loops = {"msm_accum_g1": ("msm_g1_accum.o", r"msm_accum"), "msm_accum_g2": ("msm_g2_accum.o", r"msm_accum"),
-             "ntt_pass": ("ntt.o", r"ntt_passILi"), "ntt_last_pass_abc": ("ntt.o", r"ntt_last_pass_abc")}
+             "ntt_pass": ("ntt.o", r"ntt_passILi"), "ntt_last_pass_abc": ("ntt.o", r"ntt_last_pass_abc"),
+             "spmv_binned": ("spmv.o", r"spmv_binnedILi2ELb1")}
     kernels = {}
     for k, (obj, rx) in loops.items():
         if k not in counters:
             continue
-        counts = hot_loop_mix(code_object(os.path.join(csrc, obj)), rx, whole_kernel=k.startswith("ntt"))
+        counts = hot_loop_mix(code_object(os.path.join(csrc, obj)), rx, whole_kernel=k.startswith("ntt") or k.startswith("spmv"))
         n, mix, mad_share, classes = price(counts, tab)
         c = counters[k]
         kernels[k] = {**{kk: vv for kk, vv in c.items() if kk != "counters"},
