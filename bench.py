@@ -537,8 +537,8 @@ def static_inputs(args, shard, dom):
     if args.log2n != 20 or shard:
         return out
     sha = lib_sha16()
-    for key, names in (("traffic", ("r04_pmc_hbm_traffic_2p20.json", "r03_pmc_hbm_traffic_2p20.json")),
-                       ("valu", ("r04_valu_roofline_inputs.json", "r03_valu_roofline_inputs.json"))):
+    for key, names in (("traffic", ("r05_pmc_hbm_traffic_2p20.json", "r04_pmc_hbm_traffic_2p20.json")),
+                       ("valu", ("r05_valu_roofline_inputs.json", "r04_valu_roofline_inputs.json"))):
         for name in names:
             path = os.path.join(ROOT, "profiles", name)
             try:

@@ -43,6 +43,8 @@ struct G16Env {
   int red_chunk = 0;              // G16_RED_CHUNK = 2 | 4 | 8 | 16: buckets per thread of msm_reduce1 (unset: msm_red_chunk)
   int cu_split = 0;               // G16_CU_SPLIT=k (1..24): main stream on k CUs per XCD, MSM lanes on the other 32 - k (g16hip.hip)
   int heavy_grid = 0;             // G16_HEAVY_GRID: workgroups of msm_heavy (unset: 1024 / 512; msm_stage.cuh)
+  int cz_on_the_fly = 1;          // G16_CZ_FLY=0: buildABC writes Cz with a kernel of its own instead of the quotient's first
+                                  // pass forming it while loading (ntt.cuh mul_src)
   int abc_dict = 1;               // G16_ABC_DICT=0: buildABC reads a 32-byte value per entry even when the key's coefficients
                                   // come from a small set (spmv.hip: value dictionary)
   int g2_first = -1;              // G16_G2_FIRST = 0 | 1 | 2: A1 and B1 (2: C1 too) accumulate after B2 (unset: 1 for small shards,
@@ -302,12 +304,14 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
                          size_t val_stride, g16_spmat** out);
 void g16_spmat_destroy(g16_spmat* m);
 void g16_spmat_info(const g16_spmat* m, size_t out[10]);   // dictionary size (0: plain values), virtual rows per bin
-int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out);
+// nmat == 2: d_out = Az | Bz | Cz; need_cz = false: Cz may be left unwritten (the quotient forms it on the fly)
+int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out,
+                        bool need_cz = true);
 int32_t g16_ntt_device(g16_ctx* ctx, const void* d_src, void* d_dst, uint32_t log2n, int inverse);
 // computeSnarkjsScalarCoeffs (flavour 1, prover.nim:158-181) / computeQuotientPointwise (flavour 0, :118-148)
 // d_a, d_b, d_c, d_out: n elements each (device); inputs are not modified
 int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, uint32_t log2n,
-                            int flavour, void* d_out);
+                            int flavour, void* d_out, int c_from_ab = 0);
 // one coset pipeline (shiftEvalDomain, prover.nim:109-113) and the pointwise step on separately held slices: the
 // pieces of the task-parallel quotient of a sharded proof
 int32_t g16_coset_pipeline_device(g16_ctx* ctx, const void* d_in, uint32_t log2n, void* d_out);

@@ -27,6 +27,7 @@ static G16Env read_env() {
   if (const char* v = getenv("G16_G1_BATCH")) e.g1_batch = v[0] != '0';
   if (const char* v = getenv("G16_CHAIN_CH")) e.chain_ch = v[0] != '0';
   if (const char* v = getenv("G16_ABC_DICT")) e.abc_dict = v[0] != '0';
+  if (const char* v = getenv("G16_CZ_FLY")) e.cz_on_the_fly = v[0] != '0';
   if (const char* v = getenv("G16_RED_CHUNK")) e.red_chunk = atoi(v) == 2 || atoi(v) == 4 || atoi(v) == 8 || atoi(v) == 16 ? atoi(v) : 0;
   if (const char* v = getenv("G16_TAIL_QUAD")) e.tail_quad = v[0] != '0';
   if (const char* v = getenv("G16_G2_FIRST")) e.g2_first = v[0] == '2' ? 2 : v[0] != '0';

@@ -156,12 +156,15 @@ __device__ __forceinline__ void ntt_tile_stages(u256* lds, const u256* twl, uint
 // transforms Az, Bz, Cz together (prover.nim:167-169 runs them as three tasks).
 // `scale` (last pass only): out[i] *= scale[i] instead of the plain 1/n of the inverse transform -- used
 // to fuse multiplyByPowers (prover.nim:96-106) into the inverse NTT of shiftEvalDomain (prover.nim:109-113).
+// `mul_src` (first pass of the quotient only): vector 2 of the batch is not read but FORMED while loading,
+// Cz[i] = Az[i] * Bz[i] from vectors 0 and 1 (prover.nim:69-72: buildABC's pointwise product) -- Cz is consumed by this
+// transform alone, so it never exists in HBM (no extra kernel between buildABC and the quotient, 64 n bytes less).
 template <int BLOCK>
 static __global__ void __launch_bounds__(BLOCK) ntt_pass(const u256* __restrict__ x, u256* __restrict__ y,
                                                       const u256* __restrict__ tw, uint32_t log2n, uint32_t log2s,
                                                       uint32_t rho, uint32_t log2b, int inverse, int last,
                                                       size_t xstride, size_t ystride,
-                                                      const u256* __restrict__ scale) {
+                                                      const u256* __restrict__ scale, int mul_src) {
   extern __shared__ __align__(16) unsigned char smem[];
   u256* lds = reinterpret_cast<u256*>(smem);
   x += xstride * blockIdx.y;
@@ -176,9 +179,19 @@ static __global__ void __launch_bounds__(BLOCK) ntt_pass(const u256* __restrict_
   u256* twl = lds + tile;
   for (uint32_t t = tid; t < (R >> 1); t += BLOCK) twl[t] = ntt_tw(tw, t << (log2n - rho), log2n, inverse);
   // load: element (r, b) <- x[base0 + b + nR * r]   (LDS index r*B + b)
-  for (uint32_t e = tid; e < tile; e += BLOCK) {
-    uint32_t b = e & (B - 1), r = e >> log2b;
-    lds[e] = x[(size_t)base0 + b + (size_t)nR * r];
+  if (mul_src && blockIdx.y == 2) {   // block-uniform
+    const u256* xa = x - 2 * xstride;
+    const u256* xb = x - xstride;
+    for (uint32_t e = tid; e < tile; e += BLOCK) {
+      uint32_t b = e & (B - 1), r = e >> log2b;
+      const size_t gi = (size_t)base0 + b + (size_t)nR * r;
+      lds[e] = Fr::mul(xa[gi], xb[gi]);
+    }
+  } else {
+    for (uint32_t e = tid; e < tile; e += BLOCK) {
+      uint32_t b = e & (B - 1), r = e >> log2b;
+      lds[e] = x[(size_t)base0 + b + (size_t)nR * r];
+    }
   }
   __syncthreads();
 

@@ -52,7 +52,8 @@ static int32_t ntt_kernels_init(g16_ctx* ctx) {
 // fuse_abc (forward, batch == 3 only): the last pass multiplies / subtracts the three transformed vectors on the fly
 // and writes ONE vector to `out` (ntt_last_pass_abc); fuse_abc == 2 additionally multiplies by invZ1.
 static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256* out, size_t out_stride,
-                           uint32_t batch, uint32_t log2n, int inverse, const u256* scale, int fuse_abc = 0) {
+                           uint32_t batch, uint32_t log2n, int inverse, const u256* scale, int fuse_abc = 0,
+                           int c_from_ab = 0) {
   const size_t n = size_t(1) << log2n;
   int32_t rc;
   if ((rc = ensure_twiddles(ctx, log2n))) return rc;
@@ -99,15 +100,15 @@ static int32_t ntt_batched(g16_ctx* ctx, const u256* in, size_t in_stride, u256*
     if (small)
       KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK_SMALL>, dim3(ntiles, batch),
               NTT_BLOCK_SMALL, shmem, src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse,
-              last ? 1 : 0, src_stride, dst_stride, last ? scale : (const u256*)nullptr);
+              last ? 1 : 0, src_stride, dst_stride, last ? scale : (const u256*)nullptr, p == 0 ? c_from_ab : 0);
     else if (mid)
       KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK_MID>, dim3(ntiles, batch),
               NTT_BLOCK_MID, shmem, src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse,
-              last ? 1 : 0, src_stride, dst_stride, last ? scale : (const u256*)nullptr);
+              last ? 1 : 0, src_stride, dst_stride, last ? scale : (const u256*)nullptr, p == 0 ? c_from_ab : 0);
     else
       KLAUNCH(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd", ntt_pass<NTT_BLOCK>, dim3(ntiles, batch), NTT_BLOCK, shmem,
               src, dst, (const u256*)ctx->ntt_tw.p, log2n, log2s, rho, log2b, inverse, last ? 1 : 0, src_stride,
-              dst_stride, last ? scale : (const u256*)nullptr);
+              dst_stride, last ? scale : (const u256*)nullptr, p == 0 ? c_from_ab : 0);
     src = dst;
     src_stride = dst_stride;
     log2s += rho;
@@ -144,8 +145,10 @@ static int32_t ensure_coset(g16_ctx* ctx, uint32_t log2n, int mode) {
 //   with A1*B1 - C1 fused (one vector out).
 // Az | Bz | Cz are read where they lie when they are contiguous (they are, in the per-proof buffer of
 // g16_prove_partials): no staging copies.  HBM bytes: (6 + 6 + 6 + 4) * 32 n = 704 n.
+// c_from_ab: d_c is not read -- Cz = Az * Bz is formed by the first pass while it loads (ntt.cuh, `mul_src`); needs the
+// contiguous layout Az | Bz | (room for Cz) and log2n >= 1
 int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, uint32_t log2n,
-                            int flavour, void* d_out) {
+                            int flavour, void* d_out, int c_from_ab) {
   if (log2n > 27) {
     ctx->err = "quotient needs the 2n domain: log2n <= 27";
     return G16_EINVAL;
@@ -157,6 +160,10 @@ int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, cons
   u256* X = (u256*)ctx->quot.p;   // 3n: coset coefficients  |  n: JensGroth intermediate
   u256* Y = X + 3 * n;
   const u256* in = (const u256*)d_a;
+  if (c_from_ab && ((const u256*)d_b != in + n || (const u256*)d_c != in + 2 * n || log2n == 0)) {
+    ctx->err = "quotient: Cz can only be formed on the fly from contiguous Az | Bz | Cz";
+    return G16_EINVAL;
+  }
   if ((const u256*)d_b != in + n || (const u256*)d_c != in + 2 * n) {   // scattered inputs (generic C-ABI callers)
     HIPCHK(ctx, hipMemcpyAsync(X, d_a, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(X + n, d_b, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
@@ -170,7 +177,7 @@ int32_t g16_quotient_device(g16_ctx* ctx, const void* d_a, const void* d_b, cons
   }
   // shiftEvalDomain x3 (prover.nim:109-113, 167-169): iNTT with eta^i/n folded in, then forward NTT whose last pass
   // forms A1*B1 - C1 (prover.nim:175-176) [* invZ1, prover.nim:141]
-  if ((rc = ntt_batched(ctx, in, n, X, n, 3, log2n, 1, (const u256*)ctx->coset[0].p))) return rc;
+  if ((rc = ntt_batched(ctx, in, n, X, n, 3, log2n, 1, (const u256*)ctx->coset[0].p, 0, c_from_ab))) return rc;
   if (flavour == 1) {  // Snarkjs
     if ((rc = ntt_batched(ctx, X, n, (u256*)d_out, 0, 3, log2n, 0, nullptr, 1))) return rc;
   } else {  // JensGroth: ... * invZ1, iNTT, * eta^-i   (prover.nim:141-143)

@@ -244,8 +244,10 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
 }
 
 // Az | Bz | Cz for a witness (device buffers); exposed for tests of the buildABC kernel
-static int32_t build_abc_device(g16_ctx* ctx, const g16_pkey* k, const u256* d_wit, uint32_t wit_mont, u256* d_abc) {
-  return g16_spmat_apply(ctx, k->abc, d_wit, wit_mont, d_abc);
+// need_cz = false: only Az | Bz (Montgomery); the quotient forms Cz = Az * Bz while its first pass loads (ntt.cuh)
+static int32_t build_abc_device(g16_ctx* ctx, const g16_pkey* k, const u256* d_wit, uint32_t wit_mont, u256* d_abc,
+                                bool need_cz = true) {
+  return g16_spmat_apply(ctx, k->abc, d_wit, wit_mont, d_abc, need_cz);
 }
 
 extern "C" int32_t g16_build_abc(g16_ctx* ctx, const g16_pkey* k, const void* witness, uint32_t flags, void* out_abc) {
@@ -471,15 +473,16 @@ static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* 
   // one box against the default (tools/ab_schedule.sh, profiles/r02_ab_schedule.txt): 107.6-108.5 vs 107.9-110.4
   // proofs/s and 13.1 vs 12.0 ms single-proof latency -- the quotient does finish 6 ms earlier, but the H accumulate
   // then competes with four lanes instead of running last and alone, and the proof ends no sooner.  Rejected.
+  const int fly = k->log2n >= 1 && g16_env().cz_on_the_fly ? 1 : 0;   // Cz formed by the quotient's first pass
   if (!g16_env().quotient_first) {
     if ((rc = launch_witness_sorts(ctx, k, flags))) return rc;
     if ((rc = launch_witness_msms(ctx, k, b, nullptr))) return rc;
-    if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc))) return rc;
-    if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs))) return rc;
+    if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc, fly == 0))) return rc;
+    if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs, fly))) return rc;
     return launch_h_and_collect(ctx, k, b.d_qs + k->h_lo, flags, b, out_partials);
   }
-  if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc))) return rc;
-  if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs))) return rc;
+  if ((rc = build_abc_device(ctx, k, b.d_w, wit_mont, b.d_abc, fly == 0))) return rc;
+  if ((rc = g16_quotient_device(ctx, b.d_abc, b.d_abc + n, b.d_abc + 2 * n, k->log2n, (int)k->flavour, b.d_qs, fly))) return rc;
   // ... and the bucket arrangement of the H scalars too: its dozen short kernels would otherwise queue, one after the
   // other, behind the GPU-filling accumulate waves of the four witness lanes (measured: 6 ms for a 0.5-ms sort)
   if ((rc = launch_h_sort(ctx, k, b.d_qs + k->h_lo))) return rc;
@@ -518,7 +521,7 @@ extern "C" int32_t g16_prove_partials_begin(g16_ctx* ctx, const g16_pkey* k, con
   int32_t rc = prove_bufs(ctx, k, b);
   if (!rc) rc = upload_witness(ctx, k, witness, flags, b);
   if (!rc && task_mask) {   // this rank's coset pipelines go to the GPU first: every other rank waits for their slices
-    rc = build_abc_device(ctx, k, b.d_w, (flags & G16_SCALARS_MONT) ? 1u : 0u, b.d_abc);
+    rc = build_abc_device(ctx, k, b.d_w, (flags & G16_SCALARS_MONT) ? 1u : 0u, b.d_abc, (task_mask & 4u) != 0);
     u256* out = (u256*)d_task_out;
     for (int v = 0; v < 3 && !rc; ++v)
       if (task_mask & (1u << v)) {

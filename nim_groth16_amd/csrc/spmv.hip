@@ -20,8 +20,12 @@
 //   * a lane's (up to) four products are ONE Montgomery dot product (Fr::mul4: 4 x 64 multiply-adds + one 64-mad
 //     reduction instead of four); the group then adds its lanes' sums with log2 G cross-lane steps (ds_bpermute, no
 //     LDS memory) and lane 0 writes the sum.
-//   * buildABC's pointwise Cz = Az * Bz (prover.nim:69-72) is a second, streaming kernel.  A standard-form witness
-//     (raw .wtns values) is multiplied as it is -- (v R) w / R = v w -- and that kernel brings Az, Bz to Montgomery form:
+//   * buildABC's pointwise Cz = Az * Bz (prover.nim:69-72) is NOT part of this kernel: inside a proof the quotient's
+//     first NTT pass forms it while loading (ntt.cuh `mul_src`), so Cz never exists in HBM; g16_build_abc and the
+//     task-parallel quotient of a sharded proof run the streaming kernel abc_pointwise_cz instead.
+//   * a standard-form witness (raw .wtns values) is multiplied as it is.  With a value dictionary the kernel then reads
+//     a second table holding v R^2 (the double-Montgomery form zkey files store, io.nim:134-139): (v R^2) w / R = v w R,
+//     the Montgomery sum directly; without one the sums come out in standard form and abc_pointwise_cz converts them,
 //     once per row, not once per entry.
 //   * value DICTIONARY: circuit coefficients come from a small set (+-1, MDS entries, round constants); when a key's
 //     non-zeros hold <= 65536 distinct values the entry stream is (col, value index) = 8 bytes instead of 36 and the
@@ -121,18 +125,25 @@ __global__ void __launch_bounds__(BLOCK) spmv_binned(SpmvBins bins, const uint32
   if (live && lane == 0) out[(size_t)(v % NMAT) * n + v / NMAT] = a;
 }
 
-// Cz = Az * Bz (prover.nim:69-72); x_mont == 0: the sums are in standard form (a .wtns witness): Az, Bz to Montgomery first
-__global__ void __launch_bounds__(BLOCK) abc_pointwise_cz(u256* __restrict__ abc, uint32_t x_mont, uint32_t n) {
+// Cz = Az * Bz (prover.nim:69-72); sums_mont == 0: the sums are in standard form (a .wtns witness on plain values): Az,
+// Bz to Montgomery form first; write_cz == 0: only that conversion
+__global__ void __launch_bounds__(BLOCK) abc_pointwise_cz(u256* __restrict__ abc, uint32_t sums_mont, uint32_t write_cz,
+                                                          uint32_t n) {
   const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
   if (r >= n) return;
   u256 a = abc[r], b = abc[(size_t)n + r];
-  if (!x_mont) {
+  if (!sums_mont) {
     a = Fr::to_mont(a);
     b = Fr::to_mont(b);
     abc[r] = a;
     abc[(size_t)n + r] = b;
   }
-  abc[2 * (size_t)n + r] = Fr::mul(a, b);
+  if (write_cz) abc[2 * (size_t)n + r] = Fr::mul(a, b);
+}
+
+__global__ void __launch_bounds__(BLOCK) dict_times_r(const u256* __restrict__ val, u256* __restrict__ val2, uint32_t nd) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i < nd) val2[i] = Fr::to_mont(val[i]);
 }
 
 struct Key256 {
@@ -156,13 +167,14 @@ struct g16_spmat {
   size_t nnz = 0, ndict = 0;   // ndict > 0: d_val holds the dictionary, d_vidx the per-entry indices
   uint32_t *d_ptr = nullptr, *d_col = nullptr, *d_vidx = nullptr, *d_rows = nullptr;
   u256* d_val = nullptr;
+  u256* d_val2 = nullptr;      // dictionary only: the values times R (for standard-form x: the sum is Montgomery)
   SpmvBins bins;
 };
 
 void g16_spmat_destroy(g16_spmat* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  for (void* p : {(void*)m->d_ptr, (void*)m->d_col, (void*)m->d_vidx, (void*)m->d_rows, (void*)m->d_val})
+  for (void* p : {(void*)m->d_ptr, (void*)m->d_col, (void*)m->d_vidx, (void*)m->d_rows, (void*)m->d_val, (void*)m->d_val2})
     if (p) (void)hipFree(p);
   delete m;
 }
@@ -267,6 +279,19 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
   if (!rc) rc = up((void**)&m->d_col, cols.data(), nnz * 4);
   if (!rc) rc = up((void**)&m->d_val, vals.data(), (dict ? vals.size() : nnz) * 32);
   if (!rc && dict) rc = up((void**)&m->d_vidx, vidx.data(), nnz * 4);
+  if (!rc && dict) {
+    if (hipMalloc((void**)&m->d_val2, vals.size() * 32) != hipSuccess) {
+      ctx->err = "hipMalloc(sparse matrix) failed";
+      rc = G16_ENOMEM;
+    } else {
+      hipLaunchKernelGGL(dict_times_r, dim3((uint32_t)((vals.size() + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                         m->d_val, m->d_val2, (uint32_t)vals.size());
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ctx->err = "dictionary conversion failed";
+        rc = G16_EHIP;
+      }
+    }
+  }
   if (!rc) rc = up((void**)&m->d_rows, rows.data(), nv * 4);
   if (rc) {
     g16_spmat_destroy(m);
@@ -276,17 +301,23 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
   return G16_OK;
 }
 
-// out = (nmat == 2 ? Az | Bz | Cz : y), device pointers, on the context's main stream
-int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out) {
+// out = (nmat == 2 ? Az | Bz | Cz : y), device pointers, on the context's main stream.  x_mont = 0: x in standard form
+// (nmat == 2 only).  need_cz = false: the caller forms Cz itself (the quotient's first pass): Cz is not written.
+int32_t g16_spmat_apply(g16_ctx* ctx, const g16_spmat* m, const void* d_x, uint32_t x_mont, void* d_out, bool need_cz) {
   const uint32_t nblk = m->bins.blk_off[NBINS];
   if (!nblk) return G16_OK;
+  // standard-form x: the dictionary's second table (v R) makes the sums Montgomery; plain values leave them standard
+  const u256* val = (m->ndict && !x_mont) ? m->d_val2 : m->d_val;
+  const bool sums_mont = x_mont || m->ndict;
 #define SPMV_LAUNCH(NM, DI)                                                                                          \
   KLAUNCH(ctx, NM == 2 ? "abc_spmv" : "spmv", (spmv_binned<NM, DI>), nblk, BLOCK, 0, m->bins, m->d_ptr, m->d_col,     \
-          m->d_val, m->d_vidx, (const u256*)d_x, m->d_rows, m->nrows, (u256*)d_out)
+          val, m->d_vidx, (const u256*)d_x, m->d_rows, m->nrows, (u256*)d_out)
   if (m->nmat == 2) {
     if (m->ndict) SPMV_LAUNCH(2, true);
     else SPMV_LAUNCH(2, false);
-    KLAUNCH(ctx, "abc_cz", abc_pointwise_cz, (m->nrows + BLOCK - 1) / BLOCK, BLOCK, 0, (u256*)d_out, x_mont, m->nrows);
+    if (need_cz || !sums_mont)
+      KLAUNCH(ctx, "abc_cz", abc_pointwise_cz, (m->nrows + BLOCK - 1) / BLOCK, BLOCK, 0, (u256*)d_out,
+              sums_mont ? 1u : 0u, need_cz ? 1u : 0u, m->nrows);
   } else {
     if (m->ndict) SPMV_LAUNCH(1, true);
     else SPMV_LAUNCH(1, false);

@@ -46,6 +46,10 @@ wb = F.frSeqToMontBytes(wit)
 mask = Mask(rng.fr(), rng.fr())
 pr = generateProofWithMask(0, False, zk, Witness("bn128", len(wit), wb), mask, ctx, pkey=pk)
 check_gpu_proof(orc, zk, wit, wb, mask.r, mask.s, (pr.pi_a, pr.pi_b, pr.pi_c), ctx)
+# the .wtns layout: with a value dictionary buildABC reads the v R^2 table, without one the sums are converted per row
+std = pk.prove(F.frSeqToStdBytes(wit), mont=False, r=F.frToMontBytes(mask.r), s=F.frToMontBytes(mask.s))
+assert std == (pr.pi_a, pr.pi_b, pr.pi_c)
+assert pk.build_abc(F.frSeqToStdBytes(wit), mont=False) == pk.build_abc(wb)
 import os
 assert (pk.abc_info()["dict_values"] > 0) == (os.environ.get("G16_ABC_DICT", "1") != "0")
 pk.destroy()
@@ -96,6 +100,8 @@ KNOBS = [
     {"G16_TAIL_QUAD": "1", "G16_RED_CHUNK": "2", "G16_MTAB": "1"},       # quad reduce2 in front of the one-lane merged fold
     {"G16_TAIL_QUAD": "1", "G16_MSM_WINDOW": "16"},                     # 2048 chunks per window: the 128-slot G1 variant
     {"G16_ABC_DICT": "0"},                                      # buildABC on 32-byte values although a dictionary would do
+    {"G16_CZ_FLY": "0"},                                        # Cz written by a kernel of its own (round 5, first half)
+    {"G16_CZ_FLY": "0", "G16_ABC_DICT": "0", "G16_QUOTIENT_FIRST": "1"},
 ]
 
 
