@@ -38,24 +38,26 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_valu_roofline_inputs_are_consistent():
-    """profiles/r04_valu_roofline_inputs.json (tools/valu_roofline.py) -> bench.py's roofline_valu object"""
+    """profiles/r05_valu_roofline_inputs.json (tools/valu_roofline.py) -> bench.py's roofline_valu object"""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    inp = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_roofline_inputs.json")))
+    inp = json.load(open(os.path.join(ROOT, "profiles", "r05_valu_roofline_inputs.json")))
     assert inp["kernels_sha16"] and inp["git"]
     # the committed counters belong to the library in the tree (when it is built): a kernel edit must come with a new
     # counter pass (tools/profile_session.sh), or bench.py will rightly report nulls
     from nim_groth16_amd._lib import device_code_sha16, lib_path
-    if os.path.exists(lib_path()) and inp["kernels_sha16"] != device_code_sha16():
-        import warnings
-        warnings.warn("profiles/r04_valu_roofline_inputs.json was measured on another build: bench.py will report "
-                      "nulls for the counter-derived roofline inputs until tools/profile_session.sh is re-run")
+    if os.path.exists(lib_path()):
+        assert inp["kernels_sha16"] == device_code_sha16(), \
+            "profiles/r05_valu_roofline_inputs.json was measured on another build: re-run tools/profile_session.sh pmc + " \
+            "tools/valu_roofline.py / tools/pmc_traffic.py (bench.py reports nulls for counter-derived inputs until then)"
+        hbm = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic_2p20.json")))
+        assert hbm["kernels_sha16"] == device_code_sha16()
     k = inp["kernels"]["msm_accum_g1"]
     assert 0.5 < k["mad_u64_share_of_valu"] < 0.7 and 3.5 < k["mix_issue_cycles_per_inst"] < 4.5
     assert 4.0 < inp["issue_cycles"]["v_mad_u64_u32"] < 5.0 and 1.8 < k["sustained_clock_ghz"] < 2.5
     r = bench.valu_roofline("msm_accum_g1", k["duration_us"] / 1e3, k["sustained_clock_ghz"],
-                            {"valu": inp, "valu_from": {"file": "profiles/r04_valu_roofline_inputs.json"}})
+                            {"valu": inp, "valu_from": {"file": "profiles/r05_valu_roofline_inputs.json"}})
     for key in ("bound", "achieved_ms", "valu_wave_insts_per_launch", "sustained_clock_ghz", "bound_ms_mix", "frac_mix",
                 "bound_ms_multiply_only", "frac_multiply_only"):
         assert key in r, key
