@@ -260,7 +260,7 @@ int32_t g16_spmv_fr(g16_ctx* ctx, const uint32_t* row, const uint32_t* col, cons
  *   g16_group_pkey_create: desc = the WHOLE key (shard_count 0 or 1); member g keeps index range g of every point set
  *   g16_group_prove: witness = nvars Fr in HOST memory (flags: G16_SCALARS_MONT or G16_SCALARS_STD), masks as g16_prove;
  *       the proof is bit-identical to g16_prove's on the unsharded key
- * A group is used by one host thread at a time.  (Python ranks over RCCL: nim_groth16_amd/distributed.py does the same
+ * A group is used by one host thread at a time; its keys may be destroyed before or after it.  (Python ranks over RCCL: nim_groth16_amd/distributed.py does the same
  * exchange with one process per GPU.) */
 typedef struct g16_group g16_group;
 typedef struct g16_group_pkey g16_group_pkey;

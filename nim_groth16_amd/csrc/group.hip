@@ -31,7 +31,8 @@ struct g16_group {
 };
 
 struct g16_group_pkey {
-  g16_group* grp = nullptr;
+  g16_group* grp = nullptr;          // identity check in g16_group_prove only: the key may outlive the group
+  std::vector<int> device;           // devices[g], for the key's own teardown
   uint32_t nvars = 0, log2n = 0, flavour = 1;
   std::vector<g16_pkey*> key;        // shard g on member g
   std::vector<void*> task_out;       // member g: its owned coset vectors (owned x n Fr), HBM of devices[g]
@@ -82,7 +83,7 @@ extern "C" void g16_group_pkey_destroy(g16_group_pkey* k) {
   if (!k) return;
   for (size_t i = 0; i < k->key.size(); ++i) {
     g16_pkey_destroy(k->key[i]);
-    if (i < k->grp->m.size()) (void)hipSetDevice(k->grp->m[i].device);
+    if (i < k->device.size()) (void)hipSetDevice(k->device[i]);
     if (i < k->task_out.size() && k->task_out[i]) (void)hipFree(k->task_out[i]);
     if (i < k->slices.size() && k->slices[i]) (void)hipFree(k->slices[i]);
   }
@@ -126,6 +127,7 @@ extern "C" int32_t g16_group_pkey_create(g16_group* g, const g16_pkey_desc* desc
   g16_group_pkey* k = new (std::nothrow) g16_group_pkey();
   if (!k) return G16_ENOMEM;
   k->grp = g;
+  for (auto& mb : g->m) k->device.push_back(mb.device);
   k->nvars = desc->nvars, k->log2n = desc->log2_domain, k->flavour = desc->flavour;
   k->key.assign(G, nullptr);
   k->task_out.assign(G, nullptr);

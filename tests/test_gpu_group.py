@@ -54,6 +54,40 @@ def test_group_proofs_equal_the_unsharded_proof(ctx, orc, flavour):
             grp.close()
 
 
+def test_chained_partial_record_keeps_its_c1_slot_at_infinity(ctx):
+    """when C1 and H1 share their bucket set the H accumulation continues C1's bucket sums and the pair is
+    reduced once: the record's H1 slot then holds H1 + C1 and its C1 slot XYZZ infinity (all zero) -- g16_prove_combine
+    sums both slots, so a non-zero C1 slot there would count C1 twice"""
+    from nim_groth16_amd import loadProvingKey
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd.fake_setup import fakeCircuitSetup
+    from nim_groth16_amd.synthetic import squaringChain
+    r1cs, wit = squaringChain((1 << 11) - 2, seed=4)
+    tox, _ = _toxic()
+    zk = fakeCircuitSetup(r1cs, tox, 1, ctx)
+    pk = loadProvingKey(zk, ctx)
+    try:
+        wb = F.frSeqToMontBytes(wit)
+        rec = pk.prove_partials(wb)
+        assert len(rec) == 768 and rec[640:768] == bytes(128) and rec[512:640] != bytes(128)
+        assert pk.prove_combine(rec, 1) == pk.prove(wb)
+    finally:
+        pk.destroy()
+
+
+def test_group_key_may_outlive_its_group(ctx):
+    from nim_groth16_amd import DeviceGroup, loadGroupKey
+    from nim_groth16_amd.fake_setup import fakeCircuitSetup
+    from nim_groth16_amd.synthetic import squaringChain
+    r1cs, _ = squaringChain((1 << 8) - 2, seed=4)
+    tox, _ = _toxic()
+    zk = fakeCircuitSetup(r1cs, tox, 1, ctx)
+    grp = DeviceGroup([0, 0])
+    gk = loadGroupKey(zk, grp)
+    grp.close()
+    gk.destroy()                                     # must not touch the group
+
+
 def test_group_argument_errors(ctx):
     from nim_groth16_amd import DeviceGroup
     from nim_groth16_amd._lib import G16Error
