@@ -31,8 +31,8 @@ struct G16Env {
   int r2_width = -1;       // G16_R2_WIDTH  0: reduce2 with 512 / 256-thread workgroups, 1: 128 / 64, 2: 64 / 64; unset:
                            // narrow inside proofs, wide for stand-alone MSMs (msm_stage.cuh)
   int ntt_tile = 2048;            // G16_NTT_TILE = 1024 | 2048 | 4096: NTT workgroup geometry (ntt.cuh)
-  // launch order of a proof (experiments; the defaults are the measured optimum, tools/ab_schedule.sh):
-  int quotient_first = 0;         // G16_QUOTIENT_FIRST=1: enqueue buildABC + quotient + sort(qs) before the witness MSMs
+  // launch order of a proof (the defaults are the measured optimum: profiles/r05_ab_quotient_first*.txt):
+  int quotient_first = 1;         // G16_QUOTIENT_FIRST=0: enqueue the witness MSMs before buildABC + quotient + sort(qs) (rounds 1-4)
   int lanes_after_quotient = 0;   // G16_LANES_AFTER_QUOTIENT=1 (with the above): the witness accumulations wait for them
   int g1_batch = 0;               // G16_G1_BATCH=1: ONE batched launch sequence (blockIdx.y = MSM) for A1, B1, C1 on one stream
                                   // instead of one stream and one sequence per G1 MSM (prover.hip; measured slower)

@@ -100,7 +100,11 @@ static int32_t for_members(g16_group* g, F fn) {
   } else {
     std::vector<std::thread> th;
     th.reserve(G);
-    for (size_t i = 0; i < G; ++i) th.emplace_back([&, i] { rc[i] = fn(i); });
+    try {   // nothing throws across the C ABI: a thread that cannot be started is a failed member
+      for (size_t i = 0; i < G; ++i) th.emplace_back([&, i] { rc[i] = fn(i); });
+    } catch (...) {
+      for (size_t i = th.size(); i < G; ++i) rc[i] = G16_ENOMEM;
+    }
     for (auto& t : th) t.join();
   }
   for (size_t i = 0; i < G; ++i)
@@ -171,7 +175,13 @@ extern "C" int32_t g16_group_prove(g16_group* g, const g16_group_pkey* k, const 
   const size_t G = g->m.size();
   const size_t n = size_t(1) << k->log2n;
   const uint32_t wflags = flags & G16_SCALARS_MONT;
-  std::vector<unsigned char> records(G * G16_PARTIALS_BYTES);
+  std::vector<unsigned char> records;
+  try {
+    records.resize(G * G16_PARTIALS_BYTES);
+  } catch (...) {
+    g->err = "out of host memory";
+    return G16_ENOMEM;
+  }
   int32_t rc;
   if (k->flavour != G16_FLAVOUR_SNARKJS) {
     rc = for_members(g, [&](size_t i) {

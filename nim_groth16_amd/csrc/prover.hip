@@ -465,14 +465,15 @@ static int32_t prove_partials_impl(g16_ctx* ctx, const g16_pkey* k, const void* 
   int32_t rc;
   if ((rc = prove_bufs(ctx, k, b))) return rc;
   if ((rc = upload_witness(ctx, k, witness, flags, b))) return rc;
-  // Default order: the four witness MSMs are enqueued first, then buildABC + quotient (prover.nim:244-260) and the H
-  // MSM on the main stream, concurrently with them; replicated on every rank of a sharded proof unless the caller
-  // uses the task-parallel pair g16_prove_partials_begin / _end.
-  // The alternative below (G16_QUOTIENT_FIRST=1: the head of the longest dependency chain -- quotient -> sort(qs) -> H
-  // MSM -- goes to the GPU before the ~60 launches of the witness lanes, which optionally wait for it) was measured on
-  // one box against the default (tools/ab_schedule.sh, profiles/r02_ab_schedule.txt): 107.6-108.5 vs 107.9-110.4
-  // proofs/s and 13.1 vs 12.0 ms single-proof latency -- the quotient does finish 6 ms earlier, but the H accumulate
-  // then competes with four lanes instead of running last and alone, and the proof ends no sooner.  Rejected.
+  // Launch order.  Rounds 1-4 enqueued the four witness MSMs first and buildABC + quotient + H behind them on the main
+  // stream: with the thread-per-row buildABC of those rounds the other order lost (r02: 107.6-108.5 vs 107.9-110.4
+  // proofs/s, 13.1 vs 12.0 ms single proof).  Since round 5 the head of the longest dependency chain -- buildABC (one
+  // row-balanced launch) -> quotient (Cz formed on the fly) -> sort(qs) -> H MSM -- goes to the GPU BEFORE the ~60
+  // launches of the witness lanes: two sessions, same box, identical proof bytes: single proof 10.61 -> 10.34 and
+  // 10.67 -> 10.46 ms, proofs/s 121.5 -> 122.2 and 119.9 -> 120.3 (profiles/r05_ab_quotient_first*.txt).  Holding the
+  // lanes back until the quotient is done (G16_LANES_AFTER_QUOTIENT=1) still loses (118.5, 11.4 ms).
+  // G16_QUOTIENT_FIRST=0 restores the old order.  Replicated on every rank of a sharded proof unless the caller uses the
+  // task-parallel pair g16_prove_partials_begin / _end.
   const int fly = k->log2n >= 1 && g16_env().cz_on_the_fly ? 1 : 0;   // Cz formed by the quotient's first pass
   if (!g16_env().quotient_first) {
     if ((rc = launch_witness_sorts(ctx, k, flags))) return rc;

@@ -101,7 +101,8 @@ KNOBS = [
     {"G16_TAIL_QUAD": "1", "G16_MSM_WINDOW": "16"},                     # 2048 chunks per window: the 128-slot G1 variant
     {"G16_ABC_DICT": "0"},                                      # buildABC on 32-byte values although a dictionary would do
     {"G16_CZ_FLY": "0"},                                        # Cz written by a kernel of its own (round 5, first half)
-    {"G16_CZ_FLY": "0", "G16_ABC_DICT": "0", "G16_QUOTIENT_FIRST": "1"},
+    {"G16_CZ_FLY": "0", "G16_ABC_DICT": "0", "G16_QUOTIENT_FIRST": "0"},   # ... and the launch order of rounds 1-4
+    {"G16_QUOTIENT_FIRST": "0", "G16_G2_FIRST": "1"},
 ]
 
 
