@@ -71,3 +71,26 @@ def test_c_oracle_against_the_frozen_vectors(orc):
     assert orc.ntt(bytes.fromhex(n["input"]), 4, True).hex() == n["inverse"]
     abc = [b"".join(o.fr_to_mont_bytes(x % o.R) for x in REF[k]) for k in ("Az", "Bz", "Cz")]
     assert orc.quotient_snarkjs(abc[0], abc[1], abc[2], 3).hex() == VEC["quotient_toy"]["snarkjs"]
+
+
+def test_poseidon_shape_generator_and_oracle_still_produce_the_fixture():
+    """tests/golden/poseidon_shape.json: the Poseidon-shaped circuit generator (the benchmark's second workload at 2^20)
+    still emits the same circuit and witness, and the oracle the same Az / Bz / Cz for them.  (The frozen proof is
+    re-derived by make_golden.py and held against the GPU by tests/test_gpu_golden.py.)"""
+    import hashlib
+    from nim_groth16_amd.synthetic import checkWitness, poseidonMerkle
+    fx = json.load(open(os.path.join(G, "poseidon_shape.json")))
+    r1cs, wit = poseidonMerkle(**fx["args"])
+    assert (r1cs.nWires, r1cs.nConstraints) == (fx["nWires"], fx["nConstraints"]) and checkWitness(r1cs, wit)
+    enc = lambda xs: b"".join(o.fr_to_mont_bytes(x) for x in xs)          # noqa: E731
+    sha = lambda raw: hashlib.sha256(raw).hexdigest()                      # noqa: E731
+    assert enc(wit).hex() == fx["witness_mont"] and sha(enc(wit)) == fx["sha256_witness_mont"] and hex(wit[1]) == fx["root"]
+    oc = o.r1cs_to_coeffs(o.R1CS(r1cs.nWires, r1cs.nPubOut, r1cs.nPubIn, r1cs.nPrivIn, r1cs.constraints))
+    assert len(oc) == fx["ncoeffs"]
+    raw = b"".join(sorted(bytes([m]) + row.to_bytes(4, "little") + col.to_bytes(4, "little") + o.fr_to_mont_bytes(v)
+                          for (m, row, col, v) in oc))
+    assert sha(raw) == fx["sha256_sorted_coeffs"]
+    cons = r1cs.constraints
+    assert max(len(c[0]) for c in cons) == fx["max_terms_A"] and max(len(c[1]) for c in cons) == fx["max_terms_B"]
+    Az, Bz, Cz = o.build_abc(oc, 1 << fx["args"]["log2n"], wit)
+    assert (sha(enc(Az)), sha(enc(Bz)), sha(enc(Cz))) == (fx["sha256_Az"], fx["sha256_Bz"], fx["sha256_Cz"])

@@ -74,3 +74,33 @@ def test_pairing_fixture(ctx):
         poly[k] = (poly[k] + a - 9 * b) % P
         poly[k + 6] = (poly[k + 6] + b) % P
     assert [hex(c) for c in poly] == VEC["pairing_gen1_gen2_poly12"]
+
+
+def test_poseidon_shape_fixture(ctx):
+    """tests/golden/poseidon_shape.json: the row-balanced buildABC (rows of 1..13 terms, A and B binned separately, value
+    dictionary) and the proof of the small Poseidon-shaped circuit against frozen oracle outputs -- no oracle on the box"""
+    import hashlib
+    from nim_groth16_amd import Mask, Witness, extractVKey, generateProofWithMask, loadProvingKey, verifyProof
+    from nim_groth16_amd.fake_setup import ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.synthetic import poseidonMerkle
+    fx = json.load(open(os.path.join(G, "poseidon_shape.json")))
+    r1cs, wit = poseidonMerkle(**fx["args"])
+    wb = b"".join(fr(x) for x in wit)
+    assert wb.hex() == fx["witness_mont"]
+    tw = ToxicWaste(*(int(VEC["toxic_waste"][k], 16) for k in ("alpha", "beta", "gamma", "delta", "tau")))
+    zk = fakeCircuitSetup(r1cs, tw, 1, ctx)
+    assert len(zk.coeffs) == fx["ncoeffs"]
+    pk = loadProvingKey(zk, ctx)
+    try:
+        sha = lambda raw: hashlib.sha256(raw).hexdigest()                  # noqa: E731
+        for mont in (True, False):
+            w = wb if mont else b"".join((x % R).to_bytes(32, "little") for x in wit)
+            Az, Bz, Cz = pk.build_abc(w, mont=mont)
+            assert (sha(Az), sha(Bz), sha(Cz)) == (fx["sha256_Az"], fx["sha256_Bz"], fx["sha256_Cz"]), mont
+        mask = Mask(int(VEC["mask"]["r"], 16), int(VEC["mask"]["s"], 16))
+        pr = generateProofWithMask(0, False, zk, Witness("bn128", len(wit), wb), mask, ctx, pkey=pk)
+        g = fx["proof_snarkjs_masked"]
+        assert (pr.pi_a.hex(), pr.pi_b.hex(), pr.pi_c.hex()) == (g["pi_a"], g["pi_b"], g["pi_c"])
+        assert verifyProof(extractVKey(zk), pr, ctx)
+    finally:
+        pk.destroy()
