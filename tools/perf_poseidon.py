@@ -134,6 +134,11 @@ def main():
         print(f"   one proof alone, kernel time by HIP events ({tot:.2f} ms summed over streams):")
         for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])[:14]:
             print(f"      {k:24s} {v['total_ms']:8.3f} ms  ({v['calls']} launches)")
+        from nim_groth16_amd import Proof, extractVKey, verifyProof
+        pio = wb[:32 * (zk.header.npubs + 1)]
+        ok = verifyProof(extractVKey(zk), Proof(pio, *proof), ctx)
+        print(f"   GPU verifier (pairing equation, verifier.nim:31-52): {'accepts' if ok else 'REJECTS'} the proof", flush=True)
+        assert ok
         if not args.no_oracle:
             from tests.oracle_c import load_oracle
             from tests.parity import check_gpu_proof
