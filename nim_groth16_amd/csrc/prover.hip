@@ -225,7 +225,14 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
   }
   // the A and B entries in row order, rows binned by length (sum order is irrelevant mod r)
   const g16_coeff* cf = (const g16_coeff*)d->coeffs;
-  std::vector<uint32_t> vrow(d->ncoeffs ? d->ncoeffs : 1);
+  std::vector<uint32_t> vrow;
+  try {
+    vrow.resize(d->ncoeffs ? d->ncoeffs : 1);
+  } catch (const std::bad_alloc&) {
+    ctx->err = "out of host memory";
+    g16_pkey_destroy(k);
+    return G16_ENOMEM;
+  }
   for (size_t e = 0; e < d->ncoeffs; ++e) {
     if (cf[e].matrix > 1 || cf[e].row >= n || cf[e].col >= d->nvars) {
       // MatrixC entries make the reference's buildABC raise (prover.nim:67)

@@ -186,10 +186,23 @@ void g16_spmat_info(const g16_spmat* m, size_t out[1 + 9]) {
 
 // vrow[i] = nmat * row + matrix of entry i (< nmat * nrows, checked by the caller), col[i], val = 32 bytes at
 // val_base + i * val_stride.  The caller has made ctx's device current (CTX_ENTER).
+static int32_t spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
+                            size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
+                            size_t val_stride, g16_spmat** out);
 int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
                          size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
                          size_t val_stride, g16_spmat** out) {
   *out = nullptr;
+  try {   // the host-side arrangement allocates O(nnz) memory: no exception may cross the C ABI
+    return spmat_create(ctx, nmat, nrows, nnz, vrow, vrow_stride, col, col_stride, val_base, val_stride, out);
+  } catch (const std::bad_alloc&) {
+    ctx->err = "out of host memory while arranging the sparse matrix";
+    return G16_ENOMEM;
+  }
+}
+static int32_t spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
+                            size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
+                            size_t val_stride, g16_spmat** out) {
   if (nnz >= (size_t(1) << 32) || (size_t)nmat * nrows >= (size_t(1) << 32) - 1) {
     ctx->err = "sparse matrix too large (entry offsets are 32-bit)";
     return G16_EINVAL;
@@ -241,11 +254,12 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
     for (size_t p = 0; p < nnz; ++p) memcpy(&vals[p], (const char*)val_base + (size_t)order[p] * val_stride, 32);
   }
   // bins by the length of a virtual row
-  g16_spmat* m = new (std::nothrow) g16_spmat();
+  std::vector<uint8_t> bin(nv ? nv : 1);
+  std::vector<uint32_t> rows(nv ? nv : 1);
+  g16_spmat* m = new (std::nothrow) g16_spmat();   // (no allocation that can throw follows)
   if (!m) return G16_ENOMEM;
   m->device = ctx->device;
   m->nmat = nmat, m->nrows = nrows, m->nnz = nnz, m->ndict = dict ? vals.size() : 0;
-  std::vector<uint8_t> bin(nv ? nv : 1);
   uint32_t cnt[NBINS] = {0};
   for (size_t v = 0; v < nv; ++v) {
     const uint32_t b = bin_of(ptr[v + 1] - ptr[v]);
@@ -258,7 +272,6 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
     const uint32_t per = BLOCK >> bin_glog(b);
     m->bins.blk_off[b + 1] = m->bins.blk_off[b] + (cnt[b] + per - 1) / per;
   }
-  std::vector<uint32_t> rows(nv ? nv : 1);
   {
     uint32_t cur[NBINS];
     for (int b = 0; b < NBINS; ++b) cur[b] = m->bins.row_off[b];
