@@ -36,23 +36,11 @@
 
 #include "g16_internal.hpp"
 #include "ff.cuh"
+#include "spmv_params.hpp"
 
 using namespace g16;
 
 namespace {
-
-constexpr int NBINS = 9;
-constexpr uint32_t BLOCK = 256;
-
-// lanes per virtual row of bin b = 2^bin_glog(b)
-__host__ __device__ constexpr uint32_t bin_glog(uint32_t b) { return b < 3 ? 0u : b - 2; }
-inline uint32_t bin_of(uint32_t L) {
-  if (L <= 1) return 0;
-  if (L == 2) return 1;
-  uint32_t b = 2;
-  while (b < NBINS - 1 && (4u << bin_glog(b)) < L) ++b;
-  return b;
-}
 
 struct SpmvBins {
   uint32_t row_off[NBINS + 1];   // bin b: rows[row_off[b] .. row_off[b + 1])

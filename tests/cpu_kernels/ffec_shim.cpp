@@ -3,6 +3,7 @@
 #include "../../nim_groth16_amd/csrc/ec29.cuh"
 #include "../../nim_groth16_amd/csrc/pairing.cuh"
 #include "../../nim_groth16_amd/csrc/msm_params.hpp"
+#include "../../nim_groth16_amd/csrc/spmv_params.hpp"
 #include <cstring>
 #include <vector>
 using namespace g16;
@@ -65,6 +66,24 @@ uint32_t shim_bs_block_check(uint32_t nparts) {
       if (xcd[part] < 0) xcd[part] = (int)(b & 7u);
       else if (xcd[part] != (int)(b & 7u)) return 1 + b;
     }
+  }
+  return 0;
+}
+
+// the row bins of the row-balanced sparse kernel (spmv_params.hpp): -> 0, or 1 + the first row length that breaks a rule
+uint32_t shim_spmv_bins_check(uint32_t max_len) {
+  uint32_t prev = 0;
+  for (uint32_t L = 0; L <= max_len; ++L) {
+    const uint32_t b = bin_of(L);
+    if (b >= (uint32_t)NBINS || b < prev) return 1 + L;                       // monotone in L
+    prev = b;
+    const uint32_t lanes = 1u << bin_glog(b), per_trip = bin_terms(b) * lanes;
+    if (lanes > 64 || (BLOCK % lanes) != 0) return 1 + L;
+    if (b + 1 < (uint32_t)NBINS && L > per_trip) return 1 + L;               // one trip everywhere but in the last bin
+    if (b >= 3 && L <= per_trip / 2) return 1 + L;                           // groups are at least half full
+    if (b == 0 && L > 1) return 1 + L;
+    if (b == 1 && L != 2) return 1 + L;
+    if (b == 2 && (L < 3 || L > 4)) return 1 + L;
   }
   return 0;
 }

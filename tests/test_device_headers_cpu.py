@@ -225,3 +225,11 @@ def test_sort_block_order_is_a_bijection_and_keeps_a_partition_on_one_xcd(shim):
     shim.shim_bs_block_check.restype = ctypes.c_uint32
     for nparts in (8, 688, 1376, 2752, 1, 3, 10, 43):
         assert shim.shim_bs_block_check(nparts) == 0, nparts
+
+
+def test_spmv_row_bins(shim):
+    """spmv_params.hpp: the nine row bins of the row-balanced buildABC kernel -- monotone in the row length, one trip per
+    row everywhere but in the last bin, lane groups at least half full, group sizes that divide a 256-thread workgroup"""
+    shim.shim_spmv_bins_check.restype = ctypes.c_uint32
+    assert shim.shim_spmv_bins_check(100000) == 0
+
