@@ -181,6 +181,14 @@ typedef struct { /* Proof (prover.nim:37-43) minus publicIO (= witness[0..npubs]
   uint8_t pi_c[64];
 } g16_proof;
 int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* desc, g16_pkey** out);
+/* The same with ZKey.coeffs taken straight from the .zkey FILE: `section4` = section 4 as it lies on disk -- u32 count,
+ * then count x { u32 matrix, u32 row, u32 col, 32-byte value in DOUBLE Montgomery form c R^2 } (files/zkey.nim:169-192;
+ * the reference un-Montgomerys each value twice while loading, io.nim:134-139 unmarshalFrWTF) -- and desc->coeffs = NULL,
+ * desc->ncoeffs = 0.  No host arithmetic and no 48-byte records: with the point sections of the file (plain Montgomery
+ * bytes = the in-memory layout) and a raw .wtns witness (G16_SCALARS_STD) a memory-mapped .zkey / .wtns pair is proved
+ * without being parsed.  c R^2 is also exactly what buildABC multiplies a raw .wtns value with: (c R^2) w / R = c w R. */
+int32_t g16_pkey_create_zkey(g16_ctx* ctx, const g16_pkey_desc* desc, const void* section4, size_t section4_bytes,
+                             g16_pkey** out);
 void g16_pkey_destroy(g16_pkey* key);
 /* points at infinity per ProverPoints array of this key (this shard): out[0..4] = A1, B1, B2, C1, H1; out[5] = wires
  * whose B1 AND B2 points are both (0,0); out[6] / out[7] = 1 if A1 / B1+B2 run on compacted entry lists (their own

@@ -20,7 +20,7 @@ SYMBOLS = [
     "g16_points_register_g1", "g16_points_register_g2", "g16_points_register_g1_dev",
     "g16_points_register_g2_dev", "g16_points_release", "g16_points_count", "g16_points_inf_count", "g16_points_info", "g16_msm_points",
     "g16_points_check_g1", "g16_points_check_g2", "g16_fixed_base_g1", "g16_fixed_base_g2", "g16_quotient", "g16_quotient_dev", "g16_pkey_create",
-    "g16_pkey_destroy", "g16_pkey_inf_counts", "g16_prove", "g16_build_abc", "g16_pkey_abc_info", "g16_spmv_fr", "g16_prove_partials", "g16_prove_combine",
+    "g16_pkey_create_zkey", "g16_pkey_destroy", "g16_pkey_inf_counts", "g16_prove", "g16_build_abc", "g16_pkey_abc_info", "g16_spmv_fr", "g16_prove_partials", "g16_prove_combine",
     "g16_prove_partials_begin", "g16_prove_partials_end",
     "g16_ntt_fr", "g16_ntt_fr_dev", "g16_profile_enable", "g16_profile_reset", "g16_profile_report", "g16_profile_clock",
     "g16_vkey_create", "g16_vkey_destroy", "g16_verify", "g16_pairing",
@@ -140,6 +140,7 @@ def load_library():
     lib.g16_quotient.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     lib.g16_quotient_dev.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     lib.g16_pkey_create.argtypes = [vp, ctypes.POINTER(PkeyDesc), ctypes.POINTER(vp)]
+    lib.g16_pkey_create_zkey.argtypes = [vp, ctypes.POINTER(PkeyDesc), vp, sz, ctypes.POINTER(vp)]
     lib.g16_pkey_destroy.argtypes = [vp]
     lib.g16_pkey_destroy.restype = None
     lib.g16_prove.argtypes = [vp, vp, vp, u32, vp, vp, vp]
@@ -363,10 +364,16 @@ class Context:
 class ProvingKey:
     """Device-resident proving key (g16_pkey): registered ProverPoints + CSR of the A/B matrices."""
 
-    def __init__(self, ctx: Context, desc: PkeyDesc, keepalive):
+    def __init__(self, ctx: Context, desc: PkeyDesc, keepalive, section4: bytes = None):
+        """section4: the .zkey file's coefficient section as it lies on disk (g16_pkey_create_zkey); desc.coeffs must
+        then be NULL"""
         self.ctx = ctx
         h = ctypes.c_void_p()
-        ctx._check(ctx._lib.g16_pkey_create(ctx._h, ctypes.byref(desc), ctypes.byref(h)))
+        if section4 is not None:
+            ctx._check(ctx._lib.g16_pkey_create_zkey(ctx._h, ctypes.byref(desc), _buf(section4), len(section4),
+                                                     ctypes.byref(h)))
+        else:
+            ctx._check(ctx._lib.g16_pkey_create(ctx._h, ctypes.byref(desc), ctypes.byref(h)))
         self._h = h
         self.nvars, self.npubs, self.log2n = desc.nvars, desc.npubs, desc.log2_domain
         ctx._children.add(self)

@@ -301,7 +301,7 @@ int32_t g16_sum_partials_device_g2(g16_ctx* ctx, const void* d_parts, uint32_t c
 struct g16_spmat;
 int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
                          size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
-                         size_t val_stride, g16_spmat** out);
+                         size_t val_stride, g16_spmat** out, bool values_r2 = false);
 void g16_spmat_destroy(g16_spmat* m);
 void g16_spmat_info(const g16_spmat* m, size_t out[10]);   // dictionary size (0: plain values), virtual rows per bin
 // nmat == 2: d_out = Az | Bz | Cz; need_cz = false: Cz may be left unwritten (the quotient forms it on the fly)

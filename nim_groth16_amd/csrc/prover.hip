@@ -7,6 +7,7 @@
 //   mask algebra (`**`, `+=`)     prover.nim:279-302   -> O(1) curve operations on the host, as in the
 //                                                         reference (curves.nim:136-214); not a hot loop
 #include <algorithm>
+#include <cstddef>
 #include <new>
 
 #include "g16_internal.hpp"
@@ -143,18 +144,25 @@ extern "C" int32_t g16_pkey_abc_info(const g16_pkey* k, size_t out[11]) {
   return G16_OK;
 }
 
-extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pkey** out) {
-  if (!ctx) return G16_EINVAL;
-  if (!d || !out) {
-    ctx->err = "null argument";
-    return G16_EINVAL;
-  }
-  *out = nullptr;
+// where a key's A / B coefficients come from: an array of g16_coeff (values c R), or the .zkey file's section 4 as it
+// lies on disk (44-byte entries, values c R^2: files/zkey.nim:169-192, io.nim:134-139)
+struct CoeffSource {
+  const unsigned char* base = nullptr;   // first entry
+  size_t count = 0, stride = 0, value_off = 0;
+  bool values_r2 = false;
+};
+static inline uint32_t rd32(const unsigned char* p) {
+  uint32_t v;
+  memcpy(&v, p, 4);   // section 4 is not 4-byte aligned past its first entry
+  return v;
+}
+
+static int32_t pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, const CoeffSource& cs, g16_pkey** out) {
   const size_t n = size_t(1) << d->log2_domain;
   // shape rules of generateProofWithMask (prover.nim:236, 270-276)
   if (d->log2_domain > 27 || d->nvars == 0 || d->npubs + 1 > d->nvars || d->flavour > 1 || !d->pointsA1 ||
       !d->pointsB1 || !d->pointsB2 || !d->pointsH1 || (d->nvars - d->npubs - 1 > 0 && !d->pointsC1) ||
-      (d->ncoeffs && !d->coeffs) || !d->alpha1 || !d->beta1 || !d->delta1 || !d->beta2 || !d->delta2) {
+      !d->alpha1 || !d->beta1 || !d->delta1 || !d->beta2 || !d->delta2) {
     ctx->err = "bad proving-key description";
     return G16_EINVAL;
   }
@@ -224,30 +232,66 @@ extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pke
     }
   }
   // the A and B entries in row order, rows binned by length (sum order is irrelevant mod r)
-  const g16_coeff* cf = (const g16_coeff*)d->coeffs;
   std::vector<uint32_t> vrow;
   try {
-    vrow.resize(d->ncoeffs ? d->ncoeffs : 1);
+    vrow.resize(cs.count ? cs.count : 1);
   } catch (const std::bad_alloc&) {
     ctx->err = "out of host memory";
     g16_pkey_destroy(k);
     return G16_ENOMEM;
   }
-  for (size_t e = 0; e < d->ncoeffs; ++e) {
-    if (cf[e].matrix > 1 || cf[e].row >= n || cf[e].col >= d->nvars) {
+  for (size_t e = 0; e < cs.count; ++e) {
+    const unsigned char* ent = cs.base + e * cs.stride;
+    const uint32_t matrix = rd32(ent), row = rd32(ent + 4), col = rd32(ent + 8);
+    if (matrix > 1 || row >= n || col >= d->nvars) {
       // MatrixC entries make the reference's buildABC raise (prover.nim:67)
       ctx->err = "coefficient entry out of range (matrix must be 0=A or 1=B)";
       g16_pkey_destroy(k);
       return G16_EINVAL;
     }
-    vrow[e] = 2 * cf[e].row + cf[e].matrix;
+    vrow[e] = 2 * row + matrix;
   }
-  k->ncoeffs = d->ncoeffs;
-  TRY(g16_spmat_create(ctx, 2, (uint32_t)n, d->ncoeffs, vrow.data(), 4, d->ncoeffs ? &cf[0].col : nullptr,
-                       sizeof(g16_coeff), d->ncoeffs ? cf[0].value : nullptr, sizeof(g16_coeff), &k->abc));
+  k->ncoeffs = cs.count;
+  TRY(g16_spmat_create(ctx, 2, (uint32_t)n, cs.count, vrow.data(), 4, (const uint32_t*)(cs.count ? cs.base + 8 : nullptr),
+                       cs.stride, cs.count ? cs.base + cs.value_off : nullptr, cs.stride, &k->abc, cs.values_r2));
 #undef TRY
   *out = k;
   return G16_OK;
+}
+
+extern "C" int32_t g16_pkey_create(g16_ctx* ctx, const g16_pkey_desc* d, g16_pkey** out) {
+  if (!ctx) return G16_EINVAL;
+  if (!d || !out || (d->ncoeffs && !d->coeffs)) {
+    ctx->err = "null argument";
+    return G16_EINVAL;
+  }
+  *out = nullptr;
+  static_assert(sizeof(g16_coeff) == 48 && offsetof(g16_coeff, value) == 16, "g16_coeff layout");
+  CoeffSource cs;
+  cs.base = (const unsigned char*)d->coeffs, cs.count = d->ncoeffs, cs.stride = sizeof(g16_coeff), cs.value_off = 16;
+  return pkey_create(ctx, d, cs, out);
+}
+
+// the key's coefficients straight from the .zkey file: section 4 as it lies on disk -- u32 count, then count entries of
+// { u32 matrix, u32 row, u32 col, 32-byte value in DOUBLE Montgomery form } (files/zkey.nim:169-192; io.nim:134-139
+// unmarshalFrWTF).  No host arithmetic: the values go to the device as they are.
+extern "C" int32_t g16_pkey_create_zkey(g16_ctx* ctx, const g16_pkey_desc* d, const void* section4, size_t section4_bytes,
+                                        g16_pkey** out) {
+  if (!ctx) return G16_EINVAL;
+  if (!d || !out || !section4 || section4_bytes < 4 || d->coeffs || d->ncoeffs) {
+    ctx->err = "bad argument (section 4 of the .zkey in, desc.coeffs = NULL, desc.ncoeffs = 0)";
+    return G16_EINVAL;
+  }
+  *out = nullptr;
+  const unsigned char* p = (const unsigned char*)section4;
+  const size_t count = rd32(p);
+  if (section4_bytes != 4 + count * 44) {
+    ctx->err = "unexpected length of the coefficient section (4 + 44 * count bytes)";   // zkey.nim:176 asserts the same
+    return G16_EINVAL;
+  }
+  CoeffSource cs;
+  cs.base = p + 4, cs.count = count, cs.stride = 44, cs.value_off = 12, cs.values_r2 = true;
+  return pkey_create(ctx, d, cs, out);
 }
 
 // Az | Bz | Cz for a witness (device buffers); exposed for tests of the buildABC kernel

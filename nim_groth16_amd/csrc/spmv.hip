@@ -129,9 +129,10 @@ __global__ void __launch_bounds__(BLOCK) abc_pointwise_cz(u256* __restrict__ abc
   if (write_cz) abc[2 * (size_t)n + r] = Fr::mul(a, b);
 }
 
-__global__ void __launch_bounds__(BLOCK) dict_times_r(const u256* __restrict__ val, u256* __restrict__ val2, uint32_t nd) {
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < nd) val2[i] = Fr::to_mont(val[i]);
+// out[i] = in[i] * R (c R -> c R^2) or in[i] / R (c R^2 -> c R); in == out is allowed
+__global__ void __launch_bounds__(BLOCK) values_rescale(const u256* in, u256* out, size_t nd, uint32_t divide) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < nd) out[i] = divide ? Fr::from_mont(in[i]) : Fr::to_mont(in[i]);
 }
 
 struct Key256 {
@@ -176,13 +177,14 @@ void g16_spmat_info(const g16_spmat* m, size_t out[1 + 9]) {
 // val_base + i * val_stride.  The caller has made ctx's device current (CTX_ENTER).
 static int32_t spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
                             size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
-                            size_t val_stride, g16_spmat** out);
+                            size_t val_stride, g16_spmat** out, bool values_r2);
+// values_r2: the 32-byte values are c R^2 (the double-Montgomery form of a .zkey's section 4) instead of c R
 int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
                          size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
-                         size_t val_stride, g16_spmat** out) {
+                         size_t val_stride, g16_spmat** out, bool values_r2) {
   *out = nullptr;
   try {   // the host-side arrangement allocates O(nnz) memory: no exception may cross the C ABI
-    return spmat_create(ctx, nmat, nrows, nnz, vrow, vrow_stride, col, col_stride, val_base, val_stride, out);
+    return spmat_create(ctx, nmat, nrows, nnz, vrow, vrow_stride, col, col_stride, val_base, val_stride, out, values_r2);
   } catch (const std::bad_alloc&) {
     ctx->err = "out of host memory while arranging the sparse matrix";
     return G16_ENOMEM;
@@ -190,13 +192,15 @@ int32_t g16_spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz
 }
 static int32_t spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t nnz, const uint32_t* vrow,
                             size_t vrow_stride, const uint32_t* col, size_t col_stride, const void* val_base,
-                            size_t val_stride, g16_spmat** out) {
+                            size_t val_stride, g16_spmat** out, bool values_r2) {
   if (nnz >= (size_t(1) << 32) || (size_t)nmat * nrows >= (size_t(1) << 32) - 1) {
     ctx->err = "sparse matrix too large (entry offsets are 32-bit)";
     return G16_EINVAL;
   }
   auto at32 = [](const uint32_t* p, size_t stride, size_t i) {
-    return *(const uint32_t*)((const char*)p + i * stride);
+    uint32_t v;
+    memcpy(&v, (const char*)p + i * stride, 4);   // a .zkey's 44-byte entries are not 4-byte aligned
+    return v;
   };
   const size_t nv = (size_t)nmat * nrows;
   std::vector<uint32_t> ptr(nv + 1, 0);
@@ -280,18 +284,30 @@ static int32_t spmat_create(g16_ctx* ctx, uint32_t nmat, uint32_t nrows, size_t 
   if (!rc) rc = up((void**)&m->d_col, cols.data(), nnz * 4);
   if (!rc) rc = up((void**)&m->d_val, vals.data(), (dict ? vals.size() : nnz) * 32);
   if (!rc && dict) rc = up((void**)&m->d_vidx, vidx.data(), nnz * 4);
+  // d_val holds what the host handed over: c R, or (values_r2) c R^2.  The kernel wants c R in d_val and, with a
+  // dictionary, c R^2 in d_val2: one small launch rescales in the direction that is missing.
+  const size_t nvals = dict ? vals.size() : nnz;
+  auto rescale = [&](const u256* in, u256* o, uint32_t divide) {
+    if (!nvals) return;
+    hipLaunchKernelGGL(values_rescale, dim3((uint32_t)((nvals + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, in, o,
+                       nvals, divide);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      ctx->err = "coefficient rescaling failed";
+      rc = G16_EHIP;
+    }
+  };
   if (!rc && dict) {
     if (hipMalloc((void**)&m->d_val2, vals.size() * 32) != hipSuccess) {
       ctx->err = "hipMalloc(sparse matrix) failed";
       rc = G16_ENOMEM;
+    } else if (values_r2) {   // the file's bytes ARE the second table
+      if (hipMemcpy(m->d_val2, m->d_val, vals.size() * 32, hipMemcpyDeviceToDevice) != hipSuccess) rc = G16_EHIP;
+      if (!rc) rescale(m->d_val2, m->d_val, 1);
     } else {
-      hipLaunchKernelGGL(dict_times_r, dim3((uint32_t)((vals.size() + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream,
-                         m->d_val, m->d_val2, (uint32_t)vals.size());
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        ctx->err = "dictionary conversion failed";
-        rc = G16_EHIP;
-      }
+      rescale(m->d_val, m->d_val2, 0);
     }
+  } else if (!rc && values_r2) {
+    rescale(m->d_val, m->d_val, 1);   // plain values: c R^2 -> c R in place
   }
   if (!rc) rc = up((void**)&m->d_rows, rows.data(), nv * 4);
   if (rc) {

@@ -28,8 +28,10 @@ def checkZKeyPoints(zk: ZKey, ctx=None) -> None:
         assert bad is None, f"mkG{group}: {name}[{bad}] is not a G{group} curve point"
 
 
-def parseZKey(fname: str, check: bool = False, ctx=None) -> ZKey:
-    """zkey.nim:241-246"""
+def parseZKey(fname: str, check: bool = False, ctx=None, rawCoeffs: bool = False) -> ZKey:
+    """zkey.nim:241-246.  rawCoeffs: keep the coefficient section as it lies in the file (ZKey.coeffsSection4, handed to
+    the GPU unparsed by loadProvingKey -> g16_pkey_create_zkey) instead of un-Montgomerying every entry on the host
+    (io.nim:134-139): what a large key wants -- a Poseidon-Merkle circuit of 2^20 constraints has ~10^7 entries."""
     sec = parseContainer("zkey", 1, fname)
     one = lambda i: sec[i][0]                                            # noqa: E731
     s1 = one(1)                                                          # zkey.nim:104-107
@@ -71,6 +73,11 @@ def parseZKey(fname: str, check: bool = False, ctx=None) -> ZKey:
     assert ncoeffs == 0 or int(rec["m"].max()) <= 2, "invalid matrix selector"
     assert ncoeffs == 0 or int(rec["r"].max()) < domsiz, "row index out of range"
     assert ncoeffs == 0 or int(rec["c"].max()) < nvars, "column index out of range"
+    if rawCoeffs:
+        zk.coeffs, zk.coeffsSection4 = [], bytes(s4)
+        if check:
+            checkZKeyPoints(zk, ctx)
+        return zk
     raw = rec["v"].tobytes()
     # file integer = c * R^2 ; in-memory Montgomery limbs of c = c * R = file integer * R^-1   (unmarshalFrWTF)
     ms, rs, cs = rec["m"].tolist(), rec["r"].tolist(), rec["c"].tolist()

@@ -50,14 +50,15 @@ def loadProvingKey(zkey: ZKey, ctx=None, shard_index: int = 0, shard_count: int 
     assert len(pts.pointsB2) == 128 * hdr.nvars
     assert len(pts.pointsH1) == 64 * hdr.domainSize
     assert len(pts.pointsC1) == 64 * (hdr.nvars - hdr.npubs - 1)
+    raw4 = getattr(zkey, "coeffsSection4", None)      # the .zkey's coefficient section, unparsed (parseZKey rawCoeffs)
     bufs = [_cbuf(x) for x in (pts.pointsA1, pts.pointsB1, pts.pointsB2, pts.pointsC1, pts.pointsH1,
-                               packCoeffs(zkey.coeffs), spec.alpha1, spec.beta1, spec.delta1, spec.beta2,
-                               spec.delta2)]
+                               b"" if raw4 is not None else packCoeffs(zkey.coeffs), spec.alpha1, spec.beta1,
+                               spec.delta1, spec.beta2, spec.delta2)]
     addr = [ctypes.cast(b, ctypes.c_void_p) for b in bufs]
     desc = PkeyDesc(hdr.nvars, hdr.npubs, hdr.logDomainSize, hdr.flavour, addr[0], addr[1], addr[2], addr[3],
-                    addr[4], addr[5], len(zkey.coeffs), addr[6], addr[7], addr[8], addr[9], addr[10],
-                    shard_index, shard_count)
-    return ProvingKey(ctx, desc, bufs)
+                    addr[4], None if raw4 is not None else addr[5], 0 if raw4 is not None else len(zkey.coeffs),
+                    addr[6], addr[7], addr[8], addr[9], addr[10], shard_index, shard_count)
+    return ProvingKey(ctx, desc, bufs, section4=raw4)
 
 
 def loadGroupKey(zkey: ZKey, group):

@@ -46,6 +46,10 @@ class ZKey:                          # zkey_types.nim:54-59
     pointsIC: bytes = b""            # VerifierPoints, zkey_types.nim:33-34
     pPoints: ProverPoints = field(default_factory=ProverPoints)
     coeffs: List[Tuple[int, int, int, bytes]] = field(default_factory=list)   # (matrix, row, col, Fr mont bytes)
+    # alternatively the .zkey file's coefficient section as it lies on disk (u32 count + 44-byte entries, values in the
+    # double-Montgomery form of io.nim:134-139): parseZKey(rawCoeffs=True) keeps it, loadProvingKey hands it to
+    # g16_pkey_create_zkey unparsed, and `coeffs` stays empty
+    coeffsSection4: bytes = None
 
 
 class _Coeff(ctypes.Structure):      # g16_coeff (include/g16hip.h)

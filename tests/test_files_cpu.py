@@ -40,6 +40,23 @@ def test_zkey_roundtrip_and_layout(tmp_path):
     assert zk.pPoints.pointsA1 in raw and zk.pPoints.pointsB2 in raw
 
 
+def test_zkey_raw_coefficient_section(tmp_path):
+    """parseZKey(rawCoeffs=True) keeps section 4 as it lies in the file (for g16_pkey_create_zkey): the same entries as
+    the parsed form, values still in the double-Montgomery form c R^2 (io.nim:134-139)"""
+    from nim_groth16_amd.files import parseZKey, writeZKey
+    zk, _ = _toy_zkey()
+    path = str(tmp_path / "toy.zkey")
+    writeZKey(path, zk)
+    raw = parseZKey(path, rawCoeffs=True)
+    s4 = raw.coeffsSection4
+    assert raw.coeffs == [] and struct.unpack_from("<I", s4, 0)[0] == len(zk.coeffs) and len(s4) == 4 + 44 * len(zk.coeffs)
+    for i, (m, r, c, v) in enumerate(zk.coeffs):
+        assert struct.unpack_from("<III", s4, 4 + 44 * i) == (m, r, c)
+        file_int = int.from_bytes(s4[4 + 44 * i + 12: 4 + 44 * i + 44], "little")
+        assert file_int == int.from_bytes(v, "little") * o.MONT % o.R            # c R  ->  c R^2
+    assert raw.pPoints == zk.pPoints and raw.header == zk.header and raw.specPoints == zk.specPoints
+
+
 def test_zkey_parser_rejects_bad_files(tmp_path):
     from nim_groth16_amd.files import parseZKey, writeZKey
     zk, _ = _toy_zkey()

@@ -63,6 +63,54 @@ def test_native_cli_matches_python_host(ctx, tmp_path, circuit):
     assert json.load(open(tmp_path / "proof2.json"))["pi_a"] != json.load(open(tmp_path / "proof.json"))["pi_a"]
 
 
+def test_key_from_the_unparsed_coefficient_section(ctx, orc, tmp_path):
+    """g16_pkey_create_zkey: the .zkey's section 4 goes to the library as it lies on disk (44-byte entries, values c R^2:
+    files/zkey.nim:169-192, io.nim:134-139).  buildABC and the proof must equal the parsed key's, for a key that runs on a
+    value dictionary (Poseidon shape) and for one that does not (all-distinct values), for both witness layouts; a
+    malformed section is refused."""
+    from nim_groth16_amd import Mask, Witness, generateProofWithMask, loadProvingKey
+    from nim_groth16_amd import bn128 as F
+    from nim_groth16_amd._lib import G16Error
+    from nim_groth16_amd.fake_setup import R1CS, ToxicWaste, fakeCircuitSetup
+    from nim_groth16_amd.files import parseZKey, writeZKey
+    from nim_groth16_amd.synthetic import SplitMix64, poseidonMerkle
+    from nim_groth16_amd.zkey_types import packCoeffs
+    rng = SplitMix64(31)
+    tw = ToxicWaste(*[rng.fr() for _ in range(5)])
+    r, s = rng.fr(), rng.fr()
+    circuits = [poseidonMerkle(11, seed=4)]
+    nw, cons = 300, []
+    for i in range(250):                              # > 1024 entries, every value distinct: no dictionary
+        cons.append(([(1 + rng.next() % (nw - 1), rng.fr()) for _ in range(1 + i % 7)],
+                     [(1 + rng.next() % (nw - 1), rng.fr()) for _ in range(1 + i % 3)], []))
+    circuits.append((R1CS(nw, 1, 0, nw - 2, cons), [1] + [rng.fr() for _ in range(nw - 1)]))
+    for k, (r1cs, wit) in enumerate(circuits):
+        zk = fakeCircuitSetup(r1cs, tw, 1, ctx)
+        path = str(tmp_path / f"c{k}.zkey")
+        writeZKey(path, zk)
+        parsed, raw = parseZKey(path), parseZKey(path, rawCoeffs=True)
+        wb, ws = F.frSeqToMontBytes(wit), F.frSeqToStdBytes(wit)
+        pk_p, pk_r = loadProvingKey(parsed, ctx), loadProvingKey(raw, ctx)
+        try:
+            assert pk_r.abc_info() == pk_p.abc_info() and (pk_r.abc_info()["dict_values"] > 0) == (k == 0)
+            want = orc.build_abc(packCoeffs(parsed.coeffs), wb, parsed.header.logDomainSize)
+            assert pk_r.build_abc(wb) == want and pk_r.build_abc(ws, mont=False) == want
+            if k == 0:                                # (the random second circuit is not satisfied by its witness)
+                pr = generateProofWithMask(0, False, parsed, Witness("bn128", len(wit), wb), Mask(r, s), ctx, pkey=pk_p)
+                pq = generateProofWithMask(0, False, raw, Witness("bn128", len(wit), ws, std=True), Mask(r, s), ctx, pkey=pk_r)
+                assert (pq.pi_a, pq.pi_b, pq.pi_c) == (pr.pi_a, pr.pi_b, pr.pi_c)
+        finally:
+            pk_p.destroy()
+            pk_r.destroy()
+    bad = raw.coeffsSection4[:-1]
+    raw.coeffsSection4 = bad
+    with pytest.raises(G16Error):
+        loadProvingKey(raw, ctx)
+    raw.coeffsSection4 = (1).to_bytes(4, "little") + (2).to_bytes(4, "little") + bytes(40)                # matrix 2 = MatrixC
+    with pytest.raises(G16Error):
+        loadProvingKey(raw, ctx)
+
+
 def test_native_cli_rejects_bad_files(tmp_path):
     exe = _build(tmp_path)
     bad = tmp_path / "x.zkey"

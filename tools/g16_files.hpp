@@ -2,8 +2,9 @@
 // File formats restated from the reference (groth16/files/container.nim:6-20, zkey.nim:6-91, witness.nim:5-15):
 // the point sections of a .zkey are little-endian Montgomery with R = 2^256 -- byte for byte the layout the
 // library takes -- so they go from the memory map to the GPU unparsed; .wtns values are canonical little-endian
-// and are passed with G16_SCALARS_STD.  Only the section-4 coefficients need arithmetic on the host (they are
-// doubly Montgomery-encoded, bn128/io.nim:134-139): one Montgomery reduction each.
+// and are passed with G16_SCALARS_STD.  The section-4 coefficients (doubly Montgomery-encoded, bn128/io.nim:134-139) go
+// in unparsed too since g16_pkey_create_zkey; for g16_pkey_create (and the builds before round 5 that ab_prove dlopen()s)
+// convert_coeffs() turns them into g16_coeff records with one Montgomery reduction each.
 #pragma once
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -177,7 +178,9 @@ struct ZkeyFile {
   uint32_t nvars = 0, npubs = 0, domsiz = 0, log2n = 0;
   const uint8_t *alpha1 = nullptr, *beta1 = nullptr, *beta2 = nullptr, *gamma2 = nullptr, *delta1 = nullptr,
                 *delta2 = nullptr, *ic = nullptr;
-  std::vector<g16_coeff> coeffs;
+  mutable std::vector<g16_coeff> coeffs;   // only for callers of the older g16_pkey_create (ab_prove of earlier builds)
+  const uint8_t* section4 = nullptr;       // the coefficient section as it lies in the file (g16_pkey_create_zkey)
+  size_t section4_len = 0;
   explicit ZkeyFile(const char* path) : zk(path, "zkey", 1) {   // zkey.nim:104-224
     if (zk.get(1).len != 4 || u32(zk.get(1).p) != 1) die("expecting `.zkey` file for a Groth16 prover");
     Section s2 = zk.get(2);
@@ -195,9 +198,14 @@ struct ZkeyFile {
     if (s4.len < 4) die("coefficient section too short");
     const uint32_t ncoeffs = u32(s4.p);
     if (s4.len != 4 + (size_t)ncoeffs * 44) die("unexpected coefficient section length");
+    section4 = s4.p, section4_len = s4.len;   // handed to the library unparsed: no arithmetic on the host
+  }
+  // the coefficients as g16_coeff records (values c R): what g16_pkey_create of the builds before g16_pkey_create_zkey takes
+  void convert_coeffs() const {
+    const uint32_t ncoeffs = u32(section4);
     coeffs.resize(ncoeffs);
     for (uint32_t i = 0; i < ncoeffs; ++i) {
-      const uint8_t* e = s4.p + 4 + (size_t)i * 44;
+      const uint8_t* e = section4 + 4 + (size_t)i * 44;
       coeffs[i].matrix = u32(e);
       coeffs[i].row = u32(e + 4);
       coeffs[i].col = u32(e + 8);
@@ -212,14 +220,18 @@ struct ZkeyFile {
     if (s.len != psz * n) die("unexpected length of section " + std::to_string(id));
     return s.p;
   }
-  // the proving-key description of include/g16hip.h: the point sections go to the GPU as they lie in the file
-  g16_pkey_desc desc() const {
+  // the proving-key description of include/g16hip.h: the point sections go to the GPU as they lie in the file.
+  // raw_coeffs = true: desc.coeffs stays NULL and the caller passes section4 / section4_len to g16_pkey_create_zkey
+  g16_pkey_desc desc(bool raw_coeffs = false) const {
     g16_pkey_desc d;
     memset(&d, 0, sizeof d);
     d.nvars = nvars, d.npubs = npubs, d.log2_domain = log2n, d.flavour = G16_FLAVOUR_SNARKJS;  // zkey.nim:129
     d.pointsA1 = points(5, 64, nvars), d.pointsB1 = points(6, 64, nvars), d.pointsB2 = points(7, 128, nvars);
     d.pointsC1 = points(8, 64, (size_t)nvars - npubs - 1), d.pointsH1 = points(9, 64, domsiz);
-    d.coeffs = coeffs.data(), d.ncoeffs = coeffs.size();
+    if (!raw_coeffs) {
+      if (coeffs.empty()) convert_coeffs();
+      d.coeffs = coeffs.data(), d.ncoeffs = coeffs.size();
+    }
     d.alpha1 = alpha1, d.beta1 = beta1, d.delta1 = delta1, d.beta2 = beta2, d.delta2 = delta2;
     d.shard_index = 0, d.shard_count = 1;
     return d;

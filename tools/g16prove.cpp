@@ -56,12 +56,12 @@ int main(int argc, char** argv) {
     if (rc != G16_OK) die(std::string(what) + " failed: " + g16_last_error(ctx));
   };
   chk(g16_selftest(ctx), "g16_selftest");
-  g16_pkey_desc d = zf.desc();
+  g16_pkey_desc d = zf.desc(gpus.empty());   // one GPU: the coefficient section goes to the library as it lies in the file
   g16_pkey* key = nullptr;
   g16_group* grp = nullptr;
   g16_group_pkey* gkey = nullptr;
   if (gpus.empty()) {
-    chk(g16_pkey_create(ctx, &d, &key), "g16_pkey_create");
+    chk(g16_pkey_create_zkey(ctx, &d, zf.section4, zf.section4_len, &key), "g16_pkey_create_zkey");
   } else {
     if (g16_group_create(gpus.data(), (int32_t)gpus.size(), &grp) != G16_OK) die("g16_group_create failed");
     if (g16_group_pkey_create(grp, &d, &gkey) != G16_OK)

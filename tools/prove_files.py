@@ -43,7 +43,7 @@ def main():
     ctx = Context(0)
     ctx.selftest()
     t0 = time.time()
-    zkey, wtns = parseZKey(args.zkey, check=args.check, ctx=ctx), parseWitness(args.wtns)
+    zkey, wtns = parseZKey(args.zkey, check=args.check, ctx=ctx, rawCoeffs=True), parseWitness(args.wtns)
     assert wtns.nvars == zkey.header.nvars, "wrong witness length"        # prover.nim:236
     t1 = time.time()
     pkey = loadProvingKey(zkey, ctx)
