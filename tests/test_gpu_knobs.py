@@ -103,6 +103,8 @@ KNOBS = [
     {"G16_CZ_FLY": "0"},                                        # Cz written by a kernel of its own (round 5, first half)
     {"G16_CZ_FLY": "0", "G16_ABC_DICT": "0", "G16_QUOTIENT_FIRST": "0"},   # ... and the launch order of rounds 1-4
     {"G16_QUOTIENT_FIRST": "0", "G16_G2_FIRST": "1"},
+    {"G16_CU_SPLIT": "8"},                                      # main stream on 8 CUs per XCD, lanes on the rest (H on the spare lane)
+    {"G16_CU_SPLIT": "4", "G16_HEAVY_GRID": "64", "G16_QUOTIENT_FIRST": "0"},
 ]
 
 
