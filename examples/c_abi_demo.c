@@ -6,6 +6,7 @@
  *   MSM:   sum s_i * (k_i G)  ==  (sum s_i k_i) G          (points made by g16_fixed_base_g1/g2, canonical scalars)
  *   NTT:   inverse(forward(x)) == x
  *   pairing: e(2 G1, 3 G2) == e(6 G1, G2)
+ *   sparse product (the kernel of buildABC): a permutation matrix with Montgomery ones moves x's elements, empty rows give 0
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -86,7 +87,30 @@ int main(void) {
     fprintf(stderr, "pairing is not bilinear\n");
     return 1;
   }
+  /* y = M x with g16_spmv_fr: M[i][(7 i + 3) mod 256] = 1 for i < 300 except the empty rows i = 0 mod 50;
+   * 1 in Montgomery form = R mod r (frMontR, reference groth16/bn128/io.nim:91), little-endian */
+  static const uint8_t one_mont[32] = {0xfb, 0xff, 0xff, 0x4f, 0x1c, 0x34, 0x96, 0xac, 0x29, 0xcd, 0x60, 0x9f, 0x95, 0x76, 0xfc, 0x36,
+                                       0x2e, 0x46, 0x79, 0x78, 0x6f, 0xa3, 0x6e, 0x66, 0x2f, 0xdf, 0x07, 0x9a, 0xc1, 0x77, 0x0a, 0x0e};
+  enum { ROWS = 300 };
+  static uint32_t mrow[ROWS], mcol[ROWS];
+  static uint8_t mval[ROWS * 32], yv[ROWS * 32];
+  size_t nnz = 0;
+  for (uint32_t i = 0; i < ROWS; ++i) {
+    if (i % 50 == 0) continue;
+    mrow[nnz] = i, mcol[nnz] = (7 * i + 3) % 256;
+    memcpy(mval + 32 * nnz, one_mont, 32);
+    ++nnz;
+  }
+  CHECK(g16_spmv_fr(ctx, mrow, mcol, mval, nnz, x, 256, ROWS, yv));
+  for (uint32_t i = 0; i < ROWS; ++i) {
+    static const uint8_t zero[32] = {0};
+    const uint8_t* want = i % 50 == 0 ? zero : x + 32 * ((7 * i + 3) % 256);
+    if (memcmp(yv + 32 * i, want, 32)) {
+      fprintf(stderr, "sparse product mismatch in row %u\n", i);
+      return 1;
+    }
+  }
   g16_ctx_destroy(ctx);
-  printf("C ABI demo OK: MSM G1/G2 (n=%d), registered MSM, NTT round trip, pairing bilinearity\n", N);
+  printf("C ABI demo OK: MSM G1/G2 (n=%d), registered MSM, NTT round trip, pairing bilinearity, sparse product\n", N);
   return 0;
 }
