@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_2p20_final.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_2p20_final.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -35,6 +35,13 @@ def test_committed_bench_line_has_the_contract_fields():
     assert 0.5 < d["overlap_efficiency"] < 1.0 and abs(d["overlap_efficiency"] - d["accum_ms_per_proof"] / d["ms_per_step"]) < 1e-3
     g = d["roofline_gather"]
     assert g["hbm_bytes_per_launch_by_counters"] == r["traffic"] and 0.2 < g["frac"] < 1.0
+    # round 5: BASELINE config 5's workload shape as an extra key; `value` is the squaring chain's, untouched
+    p = d["poseidon_shape"]
+    assert d["value_poseidon_shape"] == p["value"] == sorted(p["runs"])[1] and p["unit"] == "proofs/s"
+    assert p["ncoeffs_per_domain_row"] > 10 and p["coefficient_dictionary_values"] > 0 and "NOT circomlib" in p["circuit"]
+    assert sum(p["rows_by_terms"].values()) == 2 << d["config"]["domain_log2"] and p["rows_by_terms"]["L<=32"] > 0
+    assert p["points_at_infinity"]["B1"] == p["points_at_infinity"]["B2"] > 0.3 * p["nvars"]
+    assert "squaring chain" in d["config"]["workload"]
 
 
 def test_valu_roofline_inputs_are_consistent():
